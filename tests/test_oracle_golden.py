@@ -1,0 +1,195 @@
+"""The oracle against the golden vectors produced by the reference's own Python code
+(tests/golden/make_golden.py) and against its own specification.  CPU only."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import synth
+
+
+def _convert(u):
+    return np.where(u == 0, np.float32(0), u.astype(np.float32) / np.float32(128) - np.float32(1)).astype(np.float32)
+
+
+def test_p1_filterbank_restatement(golden, oracle):
+    u = synth.baseband_u8(int(golden["p1_seed"]), 16 * 12500)
+    x = _convert(u)
+    fb = oracle.filterbank(x, nfft=12500)
+    np.testing.assert_allclose(fb[:, ::25], golden["p1_slice"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(fb[:4, 2155:2155 + 256], golden["p1_band"], rtol=1e-12)
+    np.testing.assert_allclose(fb.sum(axis=1), golden["p1_rowsum"], rtol=1e-12)
+
+
+def test_p1_pins_oracle_fft_and_detect(golden, oracle):
+    """K1 + K6 + square-law detect of the C oracle == the reference's NumPy channeliser
+    to fp32 accuracy (the reference computes in float64)."""
+    u = synth.baseband_u8(int(golden["p1_seed"]), 16 * 12500)
+    x = oracle.convertarray(u)
+    assert np.array_equal(x, _convert(u))
+    X = oracle.rfft(x)
+    pw = (X.real.astype(np.float32) ** 2 + X.imag.astype(np.float32) ** 2)
+    ref = golden["p1_slice"]
+    got = pw[:, ::25].astype(np.float64)
+    # power of a noise-like spectrum: compare relative to the row mean
+    scale = ref.mean(axis=1, keepdims=True)
+    assert np.abs(got - ref).max() / scale.max() < 2e-5
+    np.testing.assert_allclose(pw.sum(axis=1, dtype=np.float64), golden["p1_rowsum"], rtol=2e-6)
+
+
+def test_oracle_fft_against_numpy(oracle):
+    g = synth.gauss(21, 6 * 12500).astype(np.float32)
+    X = oracle.rfft(g)
+    R = np.fft.rfft(g.astype(np.float64).reshape(6, 12500), axis=1)
+    err = np.abs(X - R).max() / np.abs(R).max()
+    assert err < 5e-7
+    # impulse and DC known answers
+    x = np.zeros(12500, np.float32)
+    x[0] = 1
+    assert np.allclose(oracle.rfft(x), 1.0, atol=1e-6)
+    x[:] = 1
+    X = oracle.rfft(x)[0]
+    assert abs(X[0] - 12500) < 1e-2 and np.abs(X[1:]).max() < 1e-2
+    # single tone lands in one bin
+    n = np.arange(12500)
+    x = np.cos(2 * np.pi * 3000 * n / 12500).astype(np.float32)
+    X = np.abs(oracle.rfft(x)[0])
+    assert X.argmax() == 3000 and abs(X[3000] - 6250) < 0.05
+
+
+def test_p2_pfb_restatement(golden, oracle):
+    xs = synth.gauss(int(golden["p2_seed"]), 8 * 50000).astype(np.float32)
+    pf = oracle.polyphase_filterbank(xs, nchan=6250, nwindow=4)
+    assert pf.shape == (28, 6251) and pf.dtype == np.complex64
+    np.testing.assert_allclose(pf[:, ::25], golden["p2_slice"], rtol=1e-6, atol=1e-9)
+    xs2 = synth.gauss(int(golden["p2s_seed"]), 4096).astype(np.float32)
+    pf2 = oracle.polyphase_filterbank(xs2, nchan=64, nwindow=4)
+    np.testing.assert_allclose(pf2, golden["p2s_full"], rtol=1e-6, atol=1e-9)
+
+
+def test_p2_coefficients_reproduce_pfb(golden, oracle):
+    """The taps=4 FIR table (what the HIP kernel multiplies by) reproduces the
+    reference's polyphase_filterbank."""
+    taps = oracle.pfb_coefficients(nchan=6250, nwindow=4)
+    xs = synth.gauss(int(golden["p2_seed"]), 8 * 50000).astype(np.float64)
+    ns = 12500
+    for i in (0, 5, 27):
+        tmp = sum(taps[j] * xs[i * ns + j * ns:i * ns + (j + 1) * ns] for j in range(4))
+        spec = np.fft.rfft(tmp)
+        ref = golden["p2_slice"][i]
+        assert np.abs(spec[::25] - ref).max() / np.abs(ref).max() < 1e-6
+
+
+def test_h8_vdif_header_fields(golden, oracle):
+    for w, f in zip(golden["h8_words"], golden["h8_fields"]):
+        d = oracle.vdif_header_fields(w)
+        got = [d["second"], d["epoch"], d["frame"], d["frame_length"], d["frame_nsamp"],
+               d["station"], d["threadid"], d["thread"]]
+        assert got == list(f)
+
+
+def test_p3_get_data(golden, oracle):
+    nfr = 8
+    payload = synth.baseband_u8(int(golden["p3_seed"]), nfr * 5000).reshape(nfr, 5000)
+    raw = np.zeros((nfr, 5032), dtype=np.uint8)
+    for i in range(nfr):
+        raw[i, :32] = synth.vdif_header_words(100, 33, i // 2, 5, i % 2).view(np.uint8)
+        raw[i, 32:] = payload[i]
+    d = oracle.vdif_get_data(raw.ravel())
+    ref = golden["p3_plus_127p5"].astype(np.float32) - np.float32(127.5)
+    assert np.array_equal(d, ref)
+
+
+def _s1_plane(seed, nchan, ntime, dm, t0, width, amp, tsamp, fref):
+    plane = synth.gauss(seed, nchan * ntime).reshape(1, nchan, ntime).astype(np.float32)
+    freqs = ((np.arange(nchan)) * 64. / nchan + 320)[::-1]
+    delays = np.round(dm * 4.15e-3 * ((freqs * 1e-3) ** -2 - (fref * 1e-3) ** -2) / tsamp).astype(int)
+    for c in range(nchan):
+        i0 = t0 + delays[c]
+        plane[0, c, i0:i0 + width] += amp
+    return plane
+
+
+def test_s1_dedisperse_and_snr(golden, oracle):
+    seed, nchan, ntime, dm, t0, width, amp, tsamp, fref, i0, i1 = golden["s1_params"]
+    seed, nchan, ntime, t0, width, i0, i1 = map(int, (seed, nchan, ntime, t0, width, i0, i1))
+    plane = _s1_plane(seed, nchan, ntime, dm, t0, width, amp, tsamp, fref)
+    oracle.dedisperse(plane, dm, tsamp, ref_freq=fref)
+    ts = plane[0].sum(axis=0).astype(np.float64)
+    np.testing.assert_allclose(ts, golden["s1_ts"], rtol=1e-6, atol=1e-5)
+    widths, sns, locs = oracle.optimize_pulse(golden["s1_ts"], i0, i1)
+    assert np.array_equal(widths, golden["s1_widths"])
+    np.testing.assert_allclose(sns, golden["s1_sns"], rtol=1e-10)
+    assert np.array_equal(locs, golden["s1_locs"])
+    assert sns.max() > 8          # the pulse is really recovered
+    np.testing.assert_allclose(oracle.qn(golden["s1_ts"][:200]), golden["s1_qn"], rtol=1e-12)
+    np.testing.assert_allclose(oracle.tophat_smooth(golden["s1_ts"][:64].copy(), 5),
+                               golden["s1_tophat5"], rtol=1e-12)
+    assert np.array_equal(np.nonzero(oracle.chan_mask() == 0)[0], golden["s1_chan_mask_idx"])
+    a = np.arange(20.).reshape(2, 10)
+    assert np.array_equal(oracle.inplace_roll(a.copy(), 3), golden["s1_roll3"])
+    assert np.array_equal(oracle.inplace_roll(a.copy(), -4), golden["s1_rollm4"])
+
+
+def test_dagostino_constants(oracle):
+    """SURVEY.md section 8c lists the N=500 constants as the reference's macros evaluate them."""
+    c = oracle.dag_constants(0)
+    assert c["mu1"] == -0.011976047904191617
+    assert abs(c["mu2"] - 0.046583503874135831) < 1e-17
+    assert abs(c["A"] - 86.418396509885241) < 1e-12
+    assert abs(c["Z1"] - 19.720111163339915) < 1e-13
+    assert abs(c["Z2"] - 0.99742853106286455) < 1e-15
+    assert abs(c["Z3"] - 0.72175008136453844) < 1e-15
+
+
+def test_powf_third_within_one_ulp_of_libm(oracle):
+    libm = ctypes.CDLL("libm.so.6")
+    libm.powf.restype = ctypes.c_float
+    libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    third = float(np.float32(1. / 3))
+    g = synth.gauss(33, 20000)
+    ts = np.concatenate([np.exp(3 * g[:10000]), 1 + 0.2 * g[10000:]]).astype(np.float32)
+    ts = ts[ts > 0]
+    worst = 0
+    for v in ts:
+        a = np.float32(oracle.powf_third(float(v))).view(np.int32)
+        b = np.float32(libm.powf(float(v), third)).view(np.int32)
+        worst = max(worst, abs(int(a) - int(b)))
+    assert worst <= 1
+    assert oracle.powf_third(8.0) == 2.0 and oracle.powf_third(1.0) == 1.0
+    assert oracle.powf_third(0.125) == 0.5
+
+
+def test_kurtosis_tree_and_nan_path(oracle):
+    # all-zero block (a dropped frame): pow = 0, kur = NaN, dag = DAG_INF = 9 -> flagged
+    u = synth.baseband_u8(5, 2 * 12500)
+    u[500:1000] = 0
+    x = oracle.convertarray(u)
+    pw, kur = oracle.kurtosis(x)
+    assert pw[1] == 0 and np.isnan(kur[1])
+    dag = oracle.compute_dagostino(kur)
+    assert dag[1] == 9.0 and dag[1 + 25] == 9.0          # duplicated to the other pol
+    out, norms = oracle.apply_kurtosis(x, dag)
+    assert np.all(out[500:1000] == 0) and np.all(out[12500 + 500:12500 + 1000] == 0)
+    # weights are k sequential additions of 0.04f
+    nbad = int((dag[:25] > 3.0).sum())
+    w = np.float32(0)
+    for _ in range(25 - nbad):
+        w = np.float32(w + np.float32(0.04))
+    assert norms[0] == w
+    # tree order: compare block 0 against an explicit evaluation of the halving tree
+    b = x[:500]
+    d2 = np.zeros(256, np.float32)
+    d4 = np.zeros(256, np.float32)
+    a = b[:250] * b[:250]
+    t = b[250:] * b[250:]
+    d4[:250] = a * a + t * t
+    d2[:250] = a + t
+    s = 128
+    while s >= 1:
+        d2[:s] = d2[:s] + d2[s:2 * s]
+        d4[:s] = d4[:s] + d4[s:2 * s]
+        s //= 2
+    p = np.float32(d2[0] / np.float32(500))
+    assert pw[0] == p
+    assert kur[0] == np.float32(np.float32(d4[0] / np.float32(500)) / np.float32(p * p))
