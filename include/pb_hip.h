@@ -1,0 +1,172 @@
+/*
+ * pb_hip.h -- C ABI of libpb_hip.so: the MI355X baseband -> filterbank hot path.
+ *
+ * The reference (kerrm/vlite-fast) has no plugin / FFI interface for this path: it is the
+ * body of one executable, src/process_baseband.cu main() (:334-1614), calling the kernels
+ * of src/pb_kernels.cu.  The drop-in boundary is therefore the process boundary
+ * (scripts/start_process:50 -> `process_baseband -k -K -w -b -g -o -C`), and this header
+ * is what a host process -- ours in Python, or the reference's own main() with its CUDA
+ * calls replaced -- binds in place of the per-segment device code at
+ * src/process_baseband.cu:1108-1376.  Each entry point names the reference lines it
+ * replaces.
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a negative
+ * PB_E* code and leaves a message for pb_last_error(); nothing throws across the
+ * boundary (the reference is fail-stop: cudacheck -> throw 20, src/cuda_util.cu:4-12).
+ * A handle owns one GPU's state and is not thread-safe; different handles are independent.
+ *
+ * Geometry (compile-time in the reference, src/process_baseband.h:16-55):
+ *   NFFT 12500, NCHAN 6251, NSCRUNCH 8, NKURTO 500, CHANMIN 2155, CHANMAX 6250
+ *   -> 4096 output channels; a *segment* is rows_per_seg FFT rows of one antenna, both
+ *   polarisations (the reference fixes rows_per_seg = FFTS_PER_SEG = 1024 = 100 ms).
+ * Only the 4096 output channels (FFT bins 2155..6250) are carried past the FFT: the other
+ * 2155 bins never reach an output of the reference, so planes named "compact" below are
+ * [..][4096] where the reference's are [..][6251] offset by CHANMIN.
+ */
+#ifndef PB_HIP_H
+#define PB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PB_NFFT 12500
+#define PB_NCHAN 6251
+#define PB_NSCRUNCH 8
+#define PB_NKURTO 500
+#define PB_CHANMIN 2155
+#define PB_CHANMAX 6250
+#define PB_NCHANOUT 4096
+#define PB_BLK_PER_FFT 25
+#define PB_VDIF_FRAME 5032
+#define PB_VDIF_DATA 5000
+#define PB_FRAMES_PER_SEC 25600
+
+#define PB_OK 0
+#define PB_EINVAL (-22)
+#define PB_ENOMEM (-12)
+#define PB_EHIP (-5)      /* a HIP / hipFFT call failed; see pb_last_error */
+#define PB_ESTATE (-1)
+
+#define PB_FFT_LDS 0      /* in-library fixed-order radix 25x25x10 FFT in LDS (bit-exact vs oracle) */
+#define PB_FFT_HIPFFT 1   /* hipFFT/rocFFT R2C plan, as the reference uses cuFFT */
+
+typedef struct pb_handle pb_handle;
+
+typedef struct pb_config {
+    uint32_t struct_size;   /* sizeof(pb_config), for ABI growth */
+    int32_t device;         /* -g   src/process_baseband.cu:458-472 */
+    int32_t nant;           /* antennas batched on this GPU (reference: one process each) */
+    int32_t nbit;           /* -b   2 | 4 | 8              :416-425 */
+    int32_t npol;           /* -P   1 = AA+BB, 2 = AA,BB    :439-448 */
+    int32_t rfi_mode;       /* -r   0 | 1 | 2              :427-437 */
+    int32_t taps;           /* 1 = rectangular window (reference GPU path),
+                               4 = 4-tap Hamming WOLA of analysis/baseband.py:1207 */
+    int32_t fft_backend;    /* PB_FFT_LDS | PB_FFT_HIPFFT */
+    int32_t rows_per_seg;   /* FFTS_PER_SEG (1024); any positive multiple of 8 */
+    int32_t max_seg;        /* segments staged per pb_process call (>= 1) */
+    int32_t inject_frb;     /* -i   :399-401, :711-718 */
+    int32_t keep_ave;       /* also keep the fp32 pre-quantisation planes (coadd input) */
+    int32_t debug_keep;     /* keep kurtosis statistics for pb_debug_fetch */
+} pb_config;
+
+typedef struct pb_sizes {
+    uint64_t seg_samples_per_pol;  /* rows_per_seg * 12500 */
+    uint64_t input_bytes_per_seg;  /* 2 * seg_samples_per_pol */
+    uint64_t code_bytes_per_seg;   /* "trim", src/process_baseband.cu:667-675 */
+    uint64_t ave_floats_per_seg;   /* compact: (npol==1?1:2) * rows_per_seg/8 * 4096 */
+    uint64_t rows_per_seg;
+    uint64_t blocks_per_seg_pol;   /* rows_per_seg * 25 kurtosis blocks */
+    uint64_t device_bytes;         /* HBM held by the handle */
+} pb_sizes;
+
+/* per-stage device time, hipEvent pairs on the handle's stream (reference: the PROFILE
+ * stopwatch, src/process_baseband.h:9-13, src/process_baseband.cu:1538-1558) */
+#define PB_NSTAGE 8
+enum { PB_ST_KURTOSIS = 0, PB_ST_CHANNELIZE = 1, PB_ST_FFT = 2, PB_ST_INJECT = 3,
+       PB_ST_DETECT = 4, PB_ST_DEFRAME = 5, PB_ST_COADD = 6, PB_ST_H2D = 7 };
+typedef struct pb_timers {
+    double ms[PB_NSTAGE];
+    uint64_t launches[PB_NSTAGE];
+} pb_timers;
+
+/* what pb_debug_fetch can return (needs debug_keep=1 for the first three) */
+enum { PB_DBG_POW = 0,      /* float [2][nblk]   kurtosis `pow`  src/pb_kernels.cu:104 */
+       PB_DBG_KUR = 1,      /* float [2][nblk]   `kur`           :105 */
+       PB_DBG_DAG = 2,      /* float [2][nblk]   `dag`           :132 */
+       PB_DBG_FLAGS = 3,    /* uint8 [nblk]      dag > DAG_THRESH (:256), shared by both pols */
+       PB_DBG_ROWWEIGHT = 4 /* float [rows]      kur_weights after apply_kurtosis (:292) */ };
+
+void pb_config_default(pb_config *cfg);
+
+/* replaces the one-time allocations + cufftPlan1d, src/process_baseband.cu:472-709 */
+int pb_create(const pb_config *cfg, pb_handle **out);
+/* replaces :1572-1602 */
+void pb_destroy(pb_handle *h);
+const char *pb_last_error(const pb_handle *h);   /* h may be NULL: last pb_create failure */
+int pb_query(const pb_handle *h, pb_sizes *out);
+
+/* run on a caller-supplied hipStream_t (e.g. torch's current stream); NULL = own stream */
+int pb_set_stream(pb_handle *h, void *hip_stream);
+int pb_sync(pb_handle *h);
+
+/* bandpass state bp_dev / bp_kur_dev (:700-709): zero = "initialise from the next
+ * segment's mean" (src/pb_kernels.cu:406-411,444-461).  Compact [2 pols][4096]. */
+int pb_reset_bandpass(pb_handle *h, int ant);
+int pb_get_bandpass(pb_handle *h, int ant, float *bp_raw, float *bp_kur);
+int pb_set_bandpass(pb_handle *h, int ant, const float *bp_raw, const float *bp_kur);
+
+/* Stage one segment of one antenna from host memory: the two blocking H2D copies at
+ * src/process_baseband.cu:1116-1122 (pol-planar 8-bit samples). */
+int pb_submit_planar(pb_handle *h, int ant, int seg, const uint8_t *pol0, const uint8_t *pol1,
+                     size_t nsamp_per_pol);
+/* Stage from a raw 1-s ring block of 5032-B VDIF frames (the layout writer/genbase put in
+ * ring 0x40): replaces the host frame-demux loop :1015-1067 AND the H2D copies; the
+ * headers are indexed on the host, payloads are gathered on the GPU.  seg0 = first of the
+ * rows_per_seg-sized segments the block fills (10 per second at rows_per_seg = 1024).
+ * Missing frames are zero-filled (the writer's gap fill, src/writer.c:674-688). */
+int pb_submit_vdif(pb_handle *h, int ant, int seg0, const uint8_t *block, size_t nbytes);
+/* HBM-resident producers write here directly: [max_seg][2 pols][seg_samples_per_pol] u8 */
+int pb_input_dev(pb_handle *h, int ant, void **dptr, size_t *nbytes);
+
+/* All device work of the segment loop body, src/process_baseband.cu:1152-1354, for
+ * segments [0, nseg) of every antenna, asynchronously on the handle's stream.
+ * inject_now: the reference's inject_frb_now counter (:1231-1251) for segment 0 of this
+ * call (0 = none); it is advanced per segment internally. */
+int pb_process(pb_handle *h, int nseg, int inject_now);
+
+/* The D2H copies at :1370-1375.  Any pointer may be NULL.  raw_codes / kur_codes:
+ * nseg * code_bytes_per_seg; ave_*: nseg * ave_floats_per_seg (needs keep_ave);
+ * weights: nseg * rows_per_seg, kur_weights as tscrunch_weights sees them. */
+int pb_fetch(pb_handle *h, int ant, int seg0, int nseg, uint8_t *raw_codes, uint8_t *kur_codes,
+             float *weights, float *ave_raw, float *ave_kur);
+/* device addresses of the same outputs, [max_seg][..] each (stream 0 = raw, 1 = kur) */
+int pb_output_dev(pb_handle *h, int ant, int stream, void **codes, void **ave);
+
+/* Incoherent sum (replaces the external MPI coadder scripts/start_coadd:16; arithmetic
+ * unpinned): d_sum[seg][ave_floats] (+)= sum over this handle's antennas
+ * of their fp32 kur-stream planes (raw stream if rfi_mode 0).  The cross-GPU step is an
+ * RCCL reduce of d_sum done by the host (torch.distributed); then on the root:
+ * codes = sel_and_dig(d_sum / sqrt(nant_total)). */
+int pb_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate);
+int pb_coadd_finish(pb_handle *h, int nseg, const float *d_sum, int nant_total,
+                    uint8_t *codes_host);
+
+int pb_profile(pb_handle *h, int enable);
+int pb_get_timers(pb_handle *h, pb_timers *out, int reset);
+int pb_debug_fetch(pb_handle *h, int what, int ant, int seg, void *dst, size_t nbytes);
+
+/* channeliser alone, for the taps=4 parity test against polyphase_filterbank
+ * (analysis/baseband.py:1207): x is nrows+taps-1 rows of 12500 float32 on the host,
+ * out is nrows x 6251 complex64 (interleaved re,im). */
+int pb_channelize_f32(pb_handle *h, const float *x, int nrows, int taps, float *out);
+
+const char *pb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,80 @@
+"""Shared test helpers: seeded inputs and the oracle driven segment by segment."""
+import importlib
+import os
+import re
+
+import numpy as np
+
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NFFT, NCHAN, CHANMIN, NCHANOUT = 12500, 6251, 2155, 4096
+
+
+def libpb():
+    return importlib.import_module("vlite-fast_amd.libpb")
+
+
+def make_input(seed, nrows, nseg, rfi=True, dropped=True):
+    """u8 [nseg][2][nrows*12500]: genbase-like Gaussian noise; optional RFI bursts (uniform
+    +-2.5 sigma-units like add_rfi, src/genbase.cu:671-687, in a few 500-sample blocks) and
+    one zero-filled dropped frame (the u==0 -> NaN kurtosis path)."""
+    n = nrows * NFFT
+    out = np.empty((nseg, 2, n), np.uint8)
+    for s in range(nseg):
+        for p in range(2):
+            out[s, p] = synth.baseband_u8(seed * 1000 + s * 2 + p, n)
+    if rfi:
+        g = synth.splitmix64(seed + 77, 64)
+        for i in range(0, 24, 2):
+            s = int(g[i] % nseg)
+            p = int(g[i + 1] % 2)
+            b = int(g[i + 24] % (n // 500))
+            burst = synth.splitmix64(seed + i, 500)
+            amp = 60 + int(g[i + 40] % 60)
+            v = out[s, p, b * 500:(b + 1) * 500].astype(np.int64) + (burst % (2 * amp)).astype(np.int64) - amp
+            out[s, p, b * 500:(b + 1) * 500] = np.clip(v, 0, 255)
+        # a strongly flagged stretch: > 80 % of one FFT row (exercises MIN_WEIGHT) in both pols
+        s = nseg - 1
+        row = 3 % nrows
+        for p in range(2):
+            seg = out[s, p, row * NFFT:row * NFFT + 22 * 500]
+            sq = np.where((np.arange(seg.size) // 7) % 2 == 0, 200, 56)
+            seg[:] = sq
+        # one FFT row entirely flagged (weight 0)
+        row = 9 % nrows
+        for p in range(2):
+            seg = out[0, p, row * NFFT:(row + 1) * NFFT]
+            seg[:] = np.where((np.arange(seg.size) // 5) % 2 == 0, 220, 36)
+    if dropped:
+        out[min(1, nseg - 1), 1, 5000:10000] = 0
+    return out
+
+
+def oracle_run(O, data, nrows, rfi_mode=2, npol=1, nbit=8, frb_delays=None, inject_now=0):
+    """Run the oracle over data[nseg][2][n] with persistent bandpass; returns list of results."""
+    bp_raw = np.zeros(2 * NCHAN, np.float32)
+    bp_kur = np.zeros(2 * NCHAN, np.float32)
+    res = []
+    inj = inject_now
+    for s in range(data.shape[0]):
+        r = O.segment(data[s], nrows, bp_raw, bp_kur, rfi_mode=rfi_mode, npol=npol, nbit=nbit,
+                      frb_delays=frb_delays, inject_now=inj)
+        if inj > 0:
+            inj += 1
+        res.append(r)
+    return res, bp_raw, bp_kur
+
+
+def compact_ave(ave, nrows, npol):
+    """oracle fft_ave [(pol)][ntime][6251] -> compact [(pol)][ntime][4096] flattened."""
+    ntime = nrows // 8
+    a = ave.reshape((-1, ntime, NCHAN))[:, :, CHANMIN:CHANMIN + NCHANOUT]
+    return np.ascontiguousarray(a).ravel()
+
+
+def header_symbols():
+    """Every function declared in include/pb_hip.h."""
+    txt = open(os.path.join(ROOT, "include", "pb_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pb_[a-z0-9_]+)\s*\(", txt)))

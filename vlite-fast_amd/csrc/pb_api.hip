@@ -1,0 +1,628 @@
+// C ABI of libpb_hip.so (include/pb_hip.h): handle lifetime, staging, the per-call kernel
+// sequence that replaces the segment loop body of src/process_baseband.cu:1108-1376, and
+// the D2H side.  No CPU fallback exists: every entry point needs a HIP device.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "pb_internal.h"
+
+static std::string g_create_err;
+
+#define HIPCHK(h, call)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                 \
+            return PB_EHIP;                                                               \
+        }                                                                                 \
+    } while (0)
+
+static int fail(pb_handle *h, int code, const std::string &msg)
+{
+    if (h) h->err = msg;
+    else g_create_err = msg;
+    return code;
+}
+
+extern "C" const char *pb_version(void) { return "pb_hip 0.1 (gfx950)"; }
+
+extern "C" void pb_config_default(pb_config *c)
+{
+    memset(c, 0, sizeof *c);
+    c->struct_size = sizeof *c;
+    c->device = 0;
+    c->nant = 1;
+    c->nbit = 2;        // reference default NBIT, src/process_baseband.cu:31,54
+    c->npol = 1;
+    c->rfi_mode = 2;    // :351
+    c->taps = 1;
+    c->fft_backend = PB_FFT_LDS;
+    c->rows_per_seg = 1024;
+    c->max_seg = 10;
+    c->inject_frb = 0;
+    c->keep_ave = 0;
+    c->debug_keep = 0;
+}
+
+// D'Agostino constants with the reference's float/double evaluation (src/pb_kernels.cu:4-11)
+static DagConsts make_dag(float NK)
+{
+    const double mu1 = -6. / (NK + 1);
+    const float den = (NK + 1) * (NK + 1) * (NK + 3) * (NK + 5);
+    const double mu2 = (24. * NK * (NK - 2) * (NK - 3)) / den;
+    const float q = NK * NK - 5 * NK + 2;
+    const float d2 = (NK + 7) * (NK + 9);
+    const float d3 = NK * (NK - 2) * (NK - 3);
+    const double g1 = 6. * q / d2 * sqrt((6. * (NK + 3) * (NK + 5)) / d3);
+    const double A = 6. + (8. / g1) * (2. / g1 + sqrt(1. + 4. / (g1 * g1)));
+    DagConsts c;
+    c.one_m_2_over_A = (1 - 2. / A);
+    c.mu1 = mu1;
+    c.Z1 = sqrt(4.5 * A);
+    c.Z2 = 1 - 2. / (9 * A);
+    c.Z3 = sqrt(2. / (mu2 * (A - 4)));
+    return c;
+}
+
+template <class T>
+static hipError_t dmalloc(pb_handle *h, T **p, size_t n)
+{
+    if (n == 0) { *p = nullptr; return hipSuccess; }
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e == hipSuccess) h->device_bytes += n * sizeof(T);
+    return e;
+}
+
+static float2 cis_neg(double num, double den)
+{
+    const double a = 2.0 * M_PI * num / den;
+    return make_float2((float)cos(a), (float)(-sin(a)));
+}
+
+static int build_fft_tables(pb_handle *h)
+{
+    std::vector<float2> w25(25), w10(5), tw2(625), tw3(6250), post(PB_NCHAN);
+    for (int a = 0; a < 5; ++a)
+        for (int b = 0; b < 5; ++b) w25[a * 5 + b] = cis_neg((double)(a * b), 25.0);
+    for (int k = 0; k < 5; ++k) w10[k] = cis_neg((double)k, 10.0);
+    for (int r = 0; r < 25; ++r)
+        for (int k = 0; k < 25; ++k) tw2[r * 25 + k] = cis_neg((double)(r * k), 625.0);
+    for (int r = 0; r < 10; ++r)
+        for (int k = 0; k < 625; ++k) tw3[r * 625 + k] = cis_neg((double)(r * k), 6250.0);
+    for (int k = 0; k < PB_NCHAN; ++k) {
+        const double a = 2.0 * M_PI * (double)k / (double)PB_NFFT;
+        post[k] = make_float2((float)(-sin(a)), (float)(-cos(a)));
+    }
+    FftTables &t = h->ft;
+    HIPCHK(h, dmalloc(h, &t.w25, 25));
+    HIPCHK(h, dmalloc(h, &t.w10, 5));
+    HIPCHK(h, dmalloc(h, &t.tw2, 625));
+    HIPCHK(h, dmalloc(h, &t.tw3, 6250));
+    HIPCHK(h, dmalloc(h, &t.post, PB_NCHAN));
+    HIPCHK(h, hipMemcpy(t.w25, w25.data(), 25 * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(t.w10, w10.data(), 5 * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(t.tw2, tw2.data(), 625 * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(t.tw3, tw3.data(), 6250 * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(t.post, post.data(), PB_NCHAN * sizeof(float2), hipMemcpyHostToDevice));
+    t.c1 = (float)cos(2.0 * M_PI / 5.0);
+    t.c2 = (float)cos(4.0 * M_PI / 5.0);
+    t.s1 = (float)sin(2.0 * M_PI / 5.0);
+    t.s2 = (float)sin(4.0 * M_PI / 5.0);
+    // 4-tap Hamming WOLA taps of analysis/baseband.py:1207-1232 (always built: 200 KB):
+    // tap j = window[j ns : (j+1) ns] * norms[0] * (j ? norms[j] : 1), evaluated in double
+    {
+        const int ns = PB_NFFT, nw = 4;
+        std::vector<double> win((size_t)nw * ns);
+        for (size_t k = 0; k < win.size(); ++k)
+            win[k] = 0.54 - 0.46 * cos(2.0 * M_PI * (double)k / (double)(win.size() - 1));
+        double norms[4];
+        for (int j = 0; j < nw; ++j) {
+            double s = 0;
+            for (int k = 0; k < ns; ++k) s += win[(size_t)j * ns + k] * win[(size_t)j * ns + k];
+            norms[j] = 1. / s;
+        }
+        std::vector<float> taps((size_t)nw * ns);
+        for (int j = 0; j < nw; ++j)
+            for (int k = 0; k < ns; ++k)
+                taps[(size_t)j * ns + k] = (float)(win[(size_t)j * ns + k] * norms[0] * (j ? norms[j] : 1.0));
+        HIPCHK(h, dmalloc(h, &t.taps, taps.size()));
+        HIPCHK(h, hipMemcpy(t.taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return PB_OK;
+}
+
+static int create_impl(pb_handle *h)
+{
+    const pb_config &c = h->cfg;
+    HIPCHK(h, hipSetDevice(c.device));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+    HIPCHK(h, hipEventCreate(&h->ev0));
+    HIPCHK(h, hipEventCreate(&h->ev1));
+    const size_t A = h->A, S = h->S, R = h->R;
+    const size_t in_elems = A * S * 2 * h->seg_samples;
+    HIPCHK(h, dmalloc(h, &h->d_in, in_elems));
+    HIPCHK(h, dmalloc(h, &h->d_flags, A * S * h->nblk_seg));
+    HIPCHK(h, hipMemset(h->d_flags, 0, A * S * h->nblk_seg));
+    HIPCHK(h, dmalloc(h, &h->d_wrow, A * S * R));
+    {
+        // rfi_mode 0 never computes weights: every row counts fully
+        std::vector<float> ones(A * S * R, 1.0f);
+        HIPCHK(h, hipMemcpy(h->d_wrow, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (c.debug_keep) HIPCHK(h, dmalloc(h, &h->d_stats, A * 6 * S * h->nblk_seg));
+    const bool need_raw = c.rfi_mode != 1, need_kur = c.rfi_mode != 0;
+    if (c.fft_backend == PB_FFT_HIPFFT) {
+        if (need_raw) HIPCHK(h, dmalloc(h, &h->d_fraw, in_elems));
+        if (need_kur) HIPCHK(h, dmalloc(h, &h->d_fkur, in_elems));
+        const size_t xn = A * S * 2 * R * PB_NCHAN;
+        if (need_raw) HIPCHK(h, dmalloc(h, &h->d_Xraw, xn));
+        if (need_kur) HIPCHK(h, dmalloc(h, &h->d_Xkur, xn));
+    } else {
+        const size_t pn = A * S * 2 * R * PB_NCHANOUT;
+        if (need_raw) HIPCHK(h, dmalloc(h, &h->d_Praw, pn));
+        if (need_kur) HIPCHK(h, dmalloc(h, &h->d_Pkur, pn));
+    }
+    HIPCHK(h, dmalloc(h, &h->d_bp, A * 2 * 2 * PB_NCHANOUT));
+    HIPCHK(h, hipMemset(h->d_bp, 0, A * 2 * 2 * PB_NCHANOUT * sizeof(float)));  // :702,708
+    HIPCHK(h, dmalloc(h, &h->d_codes, A * 2 * S * h->trim));
+    HIPCHK(h, hipMemset(h->d_codes, 0, A * 2 * S * h->trim));
+    if (c.keep_ave) {
+        HIPCHK(h, dmalloc(h, &h->d_ave, A * 2 * S * h->ave_per_seg));
+        HIPCHK(h, hipMemset(h->d_ave, 0, A * 2 * S * h->ave_per_seg * sizeof(float)));
+    }
+    if (c.inject_frb) {
+        // set_frb_delays, src/pb_kernels.cu:338-346, DM 80 (src/process_baseband.cu:717)
+        std::vector<float> d(PB_NCHAN);
+        const float dm = 80;
+        for (int i = 0; i < PB_NCHAN; ++i) {
+            const double freq = 0.384 - (i * 0.064) / PB_NCHAN;
+            const double rate = (double)R * PB_NFFT * 10;
+            const double scale = 4.15e-3 * dm * 10 * rate / 10 / PB_NFFT;
+            d[i] = (float)(scale / (freq * freq) - scale / (0.384 * 0.384));
+        }
+        HIPCHK(h, dmalloc(h, &h->d_frb_delays, (size_t)PB_NCHAN));
+        HIPCHK(h, hipMemcpy(h->d_frb_delays, d.data(), PB_NCHAN * sizeof(float), hipMemcpyHostToDevice));
+    }
+    int rc = build_fft_tables(h);
+    if (rc) return rc;
+    h->dag = make_dag((float)PB_NKURTO);
+    return PB_OK;
+}
+
+extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
+{
+    if (!cfg || !out) return fail(nullptr, PB_EINVAL, "pb_create: null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(pb_config)) return fail(nullptr, PB_EINVAL, "pb_create: pb_config size mismatch");
+    const pb_config &c = *cfg;
+    if (!(c.nbit == 2 || c.nbit == 4 || c.nbit == 8)) return fail(nullptr, PB_EINVAL, "Unsupported NBIT!");
+    if (!(c.npol == 1 || c.npol == 2)) return fail(nullptr, PB_EINVAL, "Unsupported npol!");
+    if (c.rfi_mode < 0 || c.rfi_mode > 2) return fail(nullptr, PB_EINVAL, "Unsupported RFI mode!");
+    if (!(c.taps == 1 || c.taps == 4)) return fail(nullptr, PB_EINVAL, "taps must be 1 or 4");
+    if (c.taps == 4 && c.fft_backend != PB_FFT_LDS) return fail(nullptr, PB_EINVAL, "taps=4 needs the LDS FFT back end");
+    if (!(c.fft_backend == PB_FFT_LDS || c.fft_backend == PB_FFT_HIPFFT)) return fail(nullptr, PB_EINVAL, "bad fft_backend");
+    if (c.nant < 1 || c.max_seg < 1) return fail(nullptr, PB_EINVAL, "nant and max_seg must be >= 1");
+    if (c.rows_per_seg < 8 || c.rows_per_seg % PB_NSCRUNCH) return fail(nullptr, PB_EINVAL, "rows_per_seg must be a positive multiple of 8");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, PB_EHIP, "pb_create: no HIP device (libpb_hip has no CPU fallback)");
+    if (c.device < 0 || c.device >= ndev) return fail(nullptr, PB_EINVAL, "pb_create: bad device id");
+
+    pb_handle *h = new pb_handle();
+    h->cfg = c;
+    h->R = c.rows_per_seg;
+    h->S = c.max_seg;
+    h->A = c.nant;
+    h->seg_samples = (size_t)h->R * PB_NFFT;
+    h->nblk_seg = (size_t)h->R * PB_BLK_PER_FFT;
+    const int polfac = c.npol == 1 ? 2 : 1;
+    h->trim = (size_t)2 * h->R * PB_NCHANOUT / (polfac * PB_NSCRUNCH) / (8 / c.nbit);
+    h->ave_per_seg = (size_t)2 * h->R * PB_NCHANOUT / (polfac * PB_NSCRUNCH);
+    h->stream = nullptr;
+    h->own_stream = false;
+    h->device_bytes = 0;
+    h->d_in = h->d_vdif = h->d_flags = h->d_codes = nullptr;
+    h->d_frame_idx = nullptr;
+    h->vdif_cap = 0;
+    h->d_wrow = h->d_stats = h->d_fraw = h->d_fkur = h->d_Praw = h->d_Pkur = h->d_bp = h->d_ave = nullptr;
+    h->d_frb_delays = nullptr;
+    h->d_Xraw = h->d_Xkur = nullptr;
+    memset(&h->ft, 0, sizeof h->ft);
+    h->profile = false;
+    h->ev0 = h->ev1 = nullptr;
+    memset(&h->timers, 0, sizeof h->timers);
+    int rc = create_impl(h);
+    if (rc != PB_OK) {
+        g_create_err = h->err;
+        pb_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return PB_OK;
+}
+
+extern "C" void pb_destroy(pb_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto &kv : h->plans) hipfftDestroy(kv.second);
+    void *ptrs[] = {h->d_in, h->d_vdif, h->d_frame_idx, h->d_flags, h->d_wrow, h->d_stats, h->d_fraw,
+                    h->d_fkur, h->d_Xraw, h->d_Xkur, h->d_Praw, h->d_Pkur, h->d_bp, h->d_codes, h->d_ave,
+                    h->d_frb_delays, h->ft.w25, h->ft.w10, h->ft.tw2, h->ft.tw3, h->ft.post, h->ft.taps};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" const char *pb_last_error(const pb_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int pb_query(const pb_handle *h, pb_sizes *o)
+{
+    if (!h || !o) return PB_EINVAL;
+    o->seg_samples_per_pol = h->seg_samples;
+    o->input_bytes_per_seg = 2 * h->seg_samples;
+    o->code_bytes_per_seg = h->trim;
+    o->ave_floats_per_seg = h->ave_per_seg;
+    o->rows_per_seg = h->R;
+    o->blocks_per_seg_pol = h->nblk_seg;
+    o->device_bytes = h->device_bytes;
+    return PB_OK;
+}
+
+extern "C" int pb_set_stream(pb_handle *h, void *s)
+{
+    if (!h) return PB_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->own_stream) {
+        HIPCHK(h, hipStreamDestroy(h->stream));
+        h->own_stream = false;
+    }
+    if (s) {
+        h->stream = (hipStream_t)s;
+    } else {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    for (auto &kv : h->plans) hipfftSetStream(kv.second, h->stream);
+    return PB_OK;
+}
+
+extern "C" int pb_sync(pb_handle *h)
+{
+    if (!h) return PB_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PB_OK;
+}
+
+static int check_ant(pb_handle *h, int ant)
+{
+    if (ant < 0 || ant >= h->A) return fail(h, PB_EINVAL, "antenna index out of range");
+    return PB_OK;
+}
+
+extern "C" int pb_reset_bandpass(pb_handle *h, int ant)
+{
+    if (!h) return PB_EINVAL;
+    if (check_ant(h, ant)) return PB_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemsetAsync(h->d_bp + (size_t)ant * 4 * PB_NCHANOUT, 0, 4 * PB_NCHANOUT * sizeof(float), h->stream));
+    return PB_OK;
+}
+
+extern "C" int pb_get_bandpass(pb_handle *h, int ant, float *raw, float *kur)
+{
+    if (!h) return PB_EINVAL;
+    if (check_ant(h, ant)) return PB_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const float *b = h->d_bp + (size_t)ant * 4 * PB_NCHANOUT;
+    if (raw) HIPCHK(h, hipMemcpy(raw, b, 2 * PB_NCHANOUT * sizeof(float), hipMemcpyDeviceToHost));
+    if (kur) HIPCHK(h, hipMemcpy(kur, b + 2 * PB_NCHANOUT, 2 * PB_NCHANOUT * sizeof(float), hipMemcpyDeviceToHost));
+    return PB_OK;
+}
+
+extern "C" int pb_set_bandpass(pb_handle *h, int ant, const float *raw, const float *kur)
+{
+    if (!h) return PB_EINVAL;
+    if (check_ant(h, ant)) return PB_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float *b = h->d_bp + (size_t)ant * 4 * PB_NCHANOUT;
+    if (raw) HIPCHK(h, hipMemcpy(b, raw, 2 * PB_NCHANOUT * sizeof(float), hipMemcpyHostToDevice));
+    if (kur) HIPCHK(h, hipMemcpy(b + 2 * PB_NCHANOUT, kur, 2 * PB_NCHANOUT * sizeof(float), hipMemcpyHostToDevice));
+    return PB_OK;
+}
+
+extern "C" int pb_submit_planar(pb_handle *h, int ant, int seg, const uint8_t *pol0, const uint8_t *pol1, size_t nsamp)
+{
+    if (!h || !pol0 || !pol1) return PB_EINVAL;
+    if (check_ant(h, ant)) return PB_EINVAL;
+    if (seg < 0 || seg >= h->S) return fail(h, PB_EINVAL, "segment slot out of range");
+    if (nsamp != h->seg_samples) return fail(h, PB_EINVAL, "pb_submit_planar: nsamp must equal seg_samples_per_pol");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    uint8_t *dst = h->d_in + (((size_t)ant * h->S + seg) * 2) * h->seg_samples;
+    HIPCHK(h, hipMemcpyAsync(dst, pol0, nsamp, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dst + h->seg_samples, pol1, nsamp, hipMemcpyHostToDevice, h->stream));
+    return PB_OK;
+}
+
+extern "C" int pb_submit_vdif(pb_handle *h, int ant, int seg0, const uint8_t *block, size_t nbytes)
+{
+    if (!h || !block) return PB_EINVAL;
+    if (check_ant(h, ant)) return PB_EINVAL;
+    if (nbytes == 0 || nbytes % (2 * PB_VDIF_FRAME)) return fail(h, PB_EINVAL, "pb_submit_vdif: block is not a whole number of frame pairs");
+    const size_t nslots = nbytes / PB_VDIF_FRAME, nfr = nslots / 2;
+    if ((nfr * PB_VDIF_DATA) % h->seg_samples) return fail(h, PB_EINVAL, "pb_submit_vdif: block does not fill whole segments");
+    const size_t nsegs = nfr * PB_VDIF_DATA / h->seg_samples;
+    if (seg0 < 0 || seg0 + nsegs > (size_t)h->S) return fail(h, PB_EINVAL, "pb_submit_vdif: segments out of range");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    // index the headers: word0 bits 0-29 seconds, word1 bits 0-23 frame, word3 bits 16-25 thread
+    std::vector<int32_t> idx(2 * nfr, -1);
+    uint32_t w0, w1, w3;
+    memcpy(&w0, block, 4);
+    memcpy(&w1, block + 4, 4);
+    const int64_t sec0 = w0 & 0x3fffffff, fr0 = w1 & 0xffffff;
+    for (size_t i = 0; i < nslots; ++i) {
+        const uint8_t *p = block + i * PB_VDIF_FRAME;
+        memcpy(&w0, p, 4);
+        memcpy(&w1, p + 4, 4);
+        memcpy(&w3, p + 12, 4);
+        if (w0 & 0x80000000u) continue;  // invalid-data bit
+        const int thread = ((w3 >> 16) & 0x3ff) != 0;
+        const int64_t rel = ((int64_t)(w0 & 0x3fffffff) - sec0) * PB_FRAMES_PER_SEC + (int64_t)(w1 & 0xffffff) - fr0;
+        if (rel < 0 || rel >= (int64_t)nfr) continue;
+        idx[(size_t)thread * nfr + rel] = (int32_t)i;
+    }
+    if (h->vdif_cap < nbytes) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->d_vdif) { (void)hipFree(h->d_vdif); h->device_bytes -= h->vdif_cap; }
+        if (h->d_frame_idx) (void)hipFree(h->d_frame_idx);
+        h->d_vdif = nullptr;
+        h->d_frame_idx = nullptr;
+        HIPCHK(h, dmalloc(h, &h->d_vdif, nbytes));
+        HIPCHK(h, hipMalloc((void **)&h->d_frame_idx, 2 * nfr * sizeof(int32_t)));
+        h->vdif_cap = nbytes;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_vdif, block, nbytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_frame_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // idx is a local
+    HIPCHK(h, launch_deframe(h, ant, seg0, nfr));
+    return PB_OK;
+}
+
+extern "C" int pb_input_dev(pb_handle *h, int ant, void **dptr, size_t *nbytes)
+{
+    if (!h || !dptr) return PB_EINVAL;
+    if (check_ant(h, ant)) return PB_EINVAL;
+    *dptr = h->d_in + (size_t)ant * h->S * 2 * h->seg_samples;
+    if (nbytes) *nbytes = (size_t)h->S * 2 * h->seg_samples;
+    return PB_OK;
+}
+
+struct StageTimer {
+    pb_handle *h;
+    int stage;
+    StageTimer(pb_handle *h_, int s) : h(h_), stage(s)
+    {
+        if (h->profile) (void)hipEventRecord(h->ev0, h->stream);
+    }
+    void stop()
+    {
+        if (!h->profile) return;
+        (void)hipEventRecord(h->ev1, h->stream);
+        (void)hipEventSynchronize(h->ev1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+        h->timers.ms[stage] += ms;
+        h->timers.launches[stage] += 1;
+    }
+};
+
+static int exec_fft(pb_handle *h, int nseg)
+{
+    const long batch = (long)nseg * 2 * h->R;
+    hipfftHandle plan;
+    auto it = h->plans.find(batch);
+    if (it == h->plans.end()) {
+        int n[1] = {PB_NFFT};
+        hipfftResult r = hipfftPlanMany(&plan, 1, n, nullptr, 1, PB_NFFT, nullptr, 1, PB_NCHAN, HIPFFT_R2C, (int)batch);
+        if (r != HIPFFT_SUCCESS) return fail(h, PB_EHIP, "hipfftPlanMany failed: " + std::to_string((int)r));
+        r = hipfftSetStream(plan, h->stream);
+        if (r != HIPFFT_SUCCESS) return fail(h, PB_EHIP, "hipfftSetStream failed");
+        h->plans[batch] = plan;
+    } else {
+        plan = it->second;
+    }
+    const size_t in_ant = (size_t)h->S * 2 * h->seg_samples;
+    const size_t x_ant = (size_t)h->S * 2 * h->R * PB_NCHAN;
+    for (int a = 0; a < h->A; ++a) {
+        if (h->cfg.rfi_mode != 1) {
+            hipfftResult r = hipfftExecR2C(plan, h->d_fraw + a * in_ant, (hipfftComplex *)(h->d_Xraw + a * x_ant));
+            if (r != HIPFFT_SUCCESS) return fail(h, PB_EHIP, "hipfftExecR2C failed: " + std::to_string((int)r));
+        }
+        if (h->cfg.rfi_mode != 0) {
+            hipfftResult r = hipfftExecR2C(plan, h->d_fkur + a * in_ant, (hipfftComplex *)(h->d_Xkur + a * x_ant));
+            if (r != HIPFFT_SUCCESS) return fail(h, PB_EHIP, "hipfftExecR2C failed: " + std::to_string((int)r));
+        }
+    }
+    return PB_OK;
+}
+
+extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
+{
+    if (!h) return PB_EINVAL;
+    if (nseg < 1 || nseg > h->S) return fail(h, PB_EINVAL, "pb_process: nseg out of range");
+    if (!h->cfg.inject_frb) inject_now = 0;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const bool hipfft = h->cfg.fft_backend == PB_FFT_HIPFFT;
+    {
+        StageTimer t(h, PB_ST_KURTOSIS);
+        HIPCHK(h, launch_kurtosis_flag(h, nseg, hipfft));
+        if (h->cfg.rfi_mode) HIPCHK(h, launch_row_weights(h, nseg));
+        t.stop();
+    }
+    if (hipfft) {
+        StageTimer t(h, PB_ST_FFT);
+        int rc = exec_fft(h, nseg);
+        if (rc) return rc;
+        t.stop();
+        if (inject_now > 0) {
+            StageTimer ti(h, PB_ST_INJECT);
+            HIPCHK(h, launch_inject_c64(h, nseg, inject_now));
+            ti.stop();
+        }
+    } else {
+        StageTimer t(h, PB_ST_CHANNELIZE);
+        HIPCHK(h, launch_channelize(h, nseg, inject_now));
+        t.stop();
+    }
+    {
+        StageTimer t(h, PB_ST_DETECT);
+        HIPCHK(h, launch_detect(h, nseg, inject_now));
+        t.stop();
+    }
+    return PB_OK;
+}
+
+extern "C" int pb_fetch(pb_handle *h, int ant, int seg0, int nseg, uint8_t *raw_codes, uint8_t *kur_codes,
+                        float *weights, float *ave_raw, float *ave_kur)
+{
+    if (!h) return PB_EINVAL;
+    if (check_ant(h, ant)) return PB_EINVAL;
+    if (seg0 < 0 || nseg < 1 || seg0 + nseg > h->S) return fail(h, PB_EINVAL, "pb_fetch: segment range");
+    if ((ave_raw || ave_kur) && !h->cfg.keep_ave) return fail(h, PB_ESTATE, "pb_fetch: fp32 planes need keep_ave=1");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t S = h->S;
+    const uint8_t *c0 = h->d_codes + (((size_t)ant * 2 + 0) * S + seg0) * h->trim;
+    const uint8_t *c1 = h->d_codes + (((size_t)ant * 2 + 1) * S + seg0) * h->trim;
+    if (raw_codes) HIPCHK(h, hipMemcpy(raw_codes, c0, (size_t)nseg * h->trim, hipMemcpyDeviceToHost));
+    if (kur_codes) HIPCHK(h, hipMemcpy(kur_codes, c1, (size_t)nseg * h->trim, hipMemcpyDeviceToHost));
+    if (ave_raw) HIPCHK(h, hipMemcpy(ave_raw, h->d_ave + (((size_t)ant * 2 + 0) * S + seg0) * h->ave_per_seg,
+                                    (size_t)nseg * h->ave_per_seg * sizeof(float), hipMemcpyDeviceToHost));
+    if (ave_kur) HIPCHK(h, hipMemcpy(ave_kur, h->d_ave + (((size_t)ant * 2 + 1) * S + seg0) * h->ave_per_seg,
+                                    (size_t)nseg * h->ave_per_seg * sizeof(float), hipMemcpyDeviceToHost));
+    if (weights) {
+        // what tscrunch_weights sees: after pscrunch_weights (npol 1) rows below MIN_WEIGHT are 0
+        std::vector<float> w((size_t)nseg * h->R);
+        HIPCHK(h, hipMemcpy(w.data(), h->d_wrow + (size_t)ant * S * h->R + (size_t)seg0 * h->R,
+                            w.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < w.size(); ++i) {
+            float v = w[i];
+            if (h->cfg.npol == 1) v = ((double)v >= 0.2) ? (float)(0.5 * (double)(v + v)) : 0.f;
+            weights[i] = v;
+        }
+    }
+    return PB_OK;
+}
+
+extern "C" int pb_output_dev(pb_handle *h, int ant, int stream, void **codes, void **ave)
+{
+    if (!h) return PB_EINVAL;
+    if (check_ant(h, ant)) return PB_EINVAL;
+    if (stream < 0 || stream > 1) return fail(h, PB_EINVAL, "stream must be 0 or 1");
+    if (codes) *codes = h->d_codes + ((size_t)ant * 2 + stream) * h->S * h->trim;
+    if (ave) *ave = h->d_ave ? h->d_ave + ((size_t)ant * 2 + stream) * h->S * h->ave_per_seg : nullptr;
+    return PB_OK;
+}
+
+extern "C" int pb_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate)
+{
+    if (!h || !d_sum) return PB_EINVAL;
+    if (!h->cfg.keep_ave) return fail(h, PB_ESTATE, "pb_coadd_local needs keep_ave=1");
+    if (nseg < 1 || nseg > h->S) return fail(h, PB_EINVAL, "pb_coadd_local: nseg out of range");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    StageTimer t(h, PB_ST_COADD);
+    HIPCHK(h, launch_coadd_local(h, nseg, d_sum, accumulate));
+    t.stop();
+    return PB_OK;
+}
+
+extern "C" int pb_coadd_finish(pb_handle *h, int nseg, const float *d_sum, int nant_total, uint8_t *codes_host)
+{
+    if (!h || !d_sum || !codes_host || nant_total < 1) return PB_EINVAL;
+    if (nseg < 1 || nseg > h->S) return fail(h, PB_EINVAL, "pb_coadd_finish: nseg out of range");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    uint8_t *d_codes = nullptr;
+    HIPCHK(h, hipMalloc((void **)&d_codes, (size_t)nseg * h->trim));
+    const float scale = (float)(1.0 / sqrt((double)nant_total));
+    hipError_t e = launch_coadd_digitise(h, nseg, d_sum, scale, d_codes);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(codes_host, d_codes, (size_t)nseg * h->trim, hipMemcpyDeviceToHost);
+    (void)hipFree(d_codes);
+    HIPCHK(h, e);
+    return PB_OK;
+}
+
+extern "C" int pb_profile(pb_handle *h, int enable)
+{
+    if (!h) return PB_EINVAL;
+    h->profile = enable != 0;
+    return PB_OK;
+}
+
+extern "C" int pb_get_timers(pb_handle *h, pb_timers *out, int reset)
+{
+    if (!h || !out) return PB_EINVAL;
+    *out = h->timers;
+    if (reset) memset(&h->timers, 0, sizeof h->timers);
+    return PB_OK;
+}
+
+extern "C" int pb_debug_fetch(pb_handle *h, int what, int ant, int seg, void *dst, size_t nbytes)
+{
+    if (!h || !dst) return PB_EINVAL;
+    if (check_ant(h, ant)) return PB_EINVAL;
+    if (seg < 0 || seg >= h->S) return fail(h, PB_EINVAL, "segment out of range");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t nb = h->nblk_seg, cap = (size_t)h->S * nb;
+    if (what == PB_DBG_POW || what == PB_DBG_KUR || what == PB_DBG_DAG) {
+        if (!h->d_stats) return fail(h, PB_ESTATE, "pb_debug_fetch: statistics need debug_keep=1");
+        if (nbytes != 2 * nb * sizeof(float)) return fail(h, PB_EINVAL, "pb_debug_fetch: size");
+        for (int pol = 0; pol < 2; ++pol) {
+            const float *src = h->d_stats + (size_t)ant * 6 * cap + ((size_t)what * 2 + pol) * cap + (size_t)seg * nb;
+            HIPCHK(h, hipMemcpy((float *)dst + pol * nb, src, nb * sizeof(float), hipMemcpyDeviceToHost));
+        }
+        return PB_OK;
+    }
+    if (what == PB_DBG_FLAGS) {
+        if (nbytes != nb) return fail(h, PB_EINVAL, "pb_debug_fetch: size");
+        HIPCHK(h, hipMemcpy(dst, h->d_flags + (size_t)ant * cap + (size_t)seg * nb, nb, hipMemcpyDeviceToHost));
+        return PB_OK;
+    }
+    if (what == PB_DBG_ROWWEIGHT) {
+        if (nbytes != (size_t)h->R * sizeof(float)) return fail(h, PB_EINVAL, "pb_debug_fetch: size");
+        HIPCHK(h, hipMemcpy(dst, h->d_wrow + (size_t)ant * h->S * h->R + (size_t)seg * h->R, nbytes, hipMemcpyDeviceToHost));
+        return PB_OK;
+    }
+    return fail(h, PB_EINVAL, "pb_debug_fetch: unknown item");
+}
+
+extern "C" int pb_channelize_f32(pb_handle *h, const float *x, int nrows, int taps, float *out)
+{
+    if (!h || !x || !out || nrows < 1) return PB_EINVAL;
+    if (!(taps == 1 || taps == 4)) return fail(h, PB_EINVAL, "taps must be 1 or 4");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    float *d_x = nullptr;
+    float2 *d_o = nullptr;
+    const size_t nin = (size_t)(nrows + taps - 1) * PB_NFFT;
+    hipError_t e = hipMalloc((void **)&d_x, nin * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_o, (size_t)nrows * PB_NCHAN * sizeof(float2));
+    if (e == hipSuccess) e = hipMemcpy(d_x, x, nin * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_channelize_f32(h, d_x, nrows, taps, d_o);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_o, (size_t)nrows * PB_NCHAN * sizeof(float2), hipMemcpyDeviceToHost);
+    if (d_x) (void)hipFree(d_x);
+    if (d_o) (void)hipFree(d_o);
+    HIPCHK(h, e);
+    return PB_OK;
+}

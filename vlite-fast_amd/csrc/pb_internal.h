@@ -1,0 +1,86 @@
+// Internal declarations shared by the HIP translation units of libpb_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "pb_hip.h"
+
+// D'Agostino constants (src/pb_kernels.cu:3-12 of the reference), evaluated on the host
+// with the reference's float/double mix and handed to the kernel by value.
+struct DagConsts {
+    double one_m_2_over_A;  // (1 - 2./A)
+    double mu1;
+    double Z1, Z2, Z3;
+};
+
+struct FrbParams {
+    const float *delays;  // [6251] or nullptr
+    int since;            // nfft_since_frb for the first row of the launch
+    float width;
+    float amp;
+};
+
+// twiddle tables of the LDS FFT (all float2, built on the host in double)
+struct FftTables {
+    float2 *w25;    // [5][5]
+    float2 *w10;    // [5]
+    float2 *tw2;    // [25][25]  (r, k)
+    float2 *tw3;    // [10][625]
+    float2 *post;   // [6251]
+    float *taps;    // [4][12500] FIR taps (taps=4) or nullptr
+    float c1, c2, s1, s2;
+};
+
+struct pb_handle {
+    pb_config cfg;
+    int R;                 // rows per segment
+    int S;                 // max segments
+    int A;                 // antennas
+    size_t seg_samples;    // R * 12500
+    size_t nblk_seg;       // R * 25 (per pol)
+    size_t trim;           // code bytes per segment
+    size_t ave_per_seg;    // compact floats per segment
+    hipStream_t stream;
+    bool own_stream;
+    size_t device_bytes;
+
+    uint8_t *d_in;         // [A][S][2][seg_samples]
+    uint8_t *d_vdif;       // staging for one raw 1-s block
+    int32_t *d_frame_idx;  // [2][frames] frame -> slot in block, -1 = missing
+    size_t vdif_cap;
+    uint8_t *d_flags;      // [A][S*R*25]
+    float *d_wrow;         // [A][S*R]
+    float *d_stats;        // debug: [A][3][2][S*R*25] pow,kur,dag
+    float *d_fraw, *d_fkur;      // hipFFT path: f32 voltages, same indexing as d_in
+    float2 *d_Xraw, *d_Xkur;     // hipFFT path: [A][S][2][R][6251]
+    float *d_Praw, *d_Pkur;      // LDS path: power [A][S][2][R][4096]
+    float *d_bp;           // [A][2 streams][2 pols][4096]
+    uint8_t *d_codes;      // [A][2 streams][S][trim]
+    float *d_ave;          // [A][2 streams][S][ave_per_seg]
+    float *d_frb_delays;   // [6251]
+    FftTables ft;
+    DagConsts dag;
+    std::map<long, hipfftHandle> plans;
+
+    bool profile;
+    hipEvent_t ev0, ev1;
+    pb_timers timers;
+    std::string err;
+};
+
+// ---- launchers (each enqueues on h->stream and returns a hipError_t) ----
+hipError_t launch_kurtosis_flag(pb_handle *h, int nseg, bool write_f32);
+hipError_t launch_row_weights(pb_handle *h, int nseg);
+hipError_t launch_deframe(pb_handle *h, int ant, int seg0, size_t nframes_per_thread);
+hipError_t launch_inject_c64(pb_handle *h, int nseg, int inject_now);
+hipError_t launch_detect(pb_handle *h, int nseg, int inject_now);
+hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now);
+hipError_t launch_channelize_f32(pb_handle *h, const float *d_x, int nrows, int taps, float2 *d_out);
+hipError_t launch_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate);
+hipError_t launch_coadd_digitise(pb_handle *h, int nseg, const float *d_sum, float scale,
+                                 uint8_t *d_codes);

@@ -1,0 +1,260 @@
+"""ctypes binding of libpb_hip.so (include/pb_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is visible the
+constructor raises.  Build with `make -C vlite-fast_amd/csrc` (or __graft_entry__.build()).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpb_hip.so")
+
+NFFT = 12500
+NCHAN = 6251
+NSCRUNCH = 8
+NKURTO = 500
+CHANMIN = 2155
+CHANMAX = 6250
+NCHANOUT = 4096
+VLITE_RATE = 128000000
+FFT_LDS = 0
+FFT_HIPFFT = 1
+
+STAGES = ("kurtosis", "channelize", "fft", "inject", "detect", "deframe", "coadd", "h2d")
+DBG_POW, DBG_KUR, DBG_DAG, DBG_FLAGS, DBG_ROWWEIGHT = range(5)
+
+
+class PbError(RuntimeError):
+    pass
+
+
+class PbConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("nant", C.c_int32),
+                ("nbit", C.c_int32), ("npol", C.c_int32), ("rfi_mode", C.c_int32),
+                ("taps", C.c_int32), ("fft_backend", C.c_int32), ("rows_per_seg", C.c_int32),
+                ("max_seg", C.c_int32), ("inject_frb", C.c_int32), ("keep_ave", C.c_int32),
+                ("debug_keep", C.c_int32)]
+
+
+class PbSizes(C.Structure):
+    _fields_ = [("seg_samples_per_pol", C.c_uint64), ("input_bytes_per_seg", C.c_uint64),
+                ("code_bytes_per_seg", C.c_uint64), ("ave_floats_per_seg", C.c_uint64),
+                ("rows_per_seg", C.c_uint64), ("blocks_per_seg_pol", C.c_uint64),
+                ("device_bytes", C.c_uint64)]
+
+
+class PbTimers(C.Structure):
+    _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8)]
+
+
+EXPORTS = ["pb_config_default", "pb_create", "pb_destroy", "pb_last_error", "pb_query",
+           "pb_set_stream", "pb_sync", "pb_reset_bandpass", "pb_get_bandpass", "pb_set_bandpass",
+           "pb_submit_planar", "pb_submit_vdif", "pb_input_dev", "pb_process", "pb_fetch",
+           "pb_output_dev", "pb_coadd_local", "pb_coadd_finish", "pb_profile", "pb_get_timers",
+           "pb_debug_fetch", "pb_channelize_f32", "pb_version"]
+
+_lib = None
+
+
+def load():
+    """dlopen libpb_hip.so and declare every prototype.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PbError("%s not found: build it with `make -C vlite-fast_amd/csrc`; "
+                      "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u8p, fp = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_float)
+    L.pb_config_default.argtypes = [C.POINTER(PbConfig)]
+    L.pb_config_default.restype = None
+    L.pb_create.argtypes = [C.POINTER(PbConfig), C.POINTER(vp)]
+    L.pb_destroy.argtypes = [vp]
+    L.pb_destroy.restype = None
+    L.pb_last_error.argtypes = [vp]
+    L.pb_last_error.restype = C.c_char_p
+    L.pb_query.argtypes = [vp, C.POINTER(PbSizes)]
+    L.pb_set_stream.argtypes = [vp, vp]
+    L.pb_sync.argtypes = [vp]
+    L.pb_reset_bandpass.argtypes = [vp, C.c_int]
+    L.pb_get_bandpass.argtypes = [vp, C.c_int, fp, fp]
+    L.pb_set_bandpass.argtypes = [vp, C.c_int, fp, fp]
+    L.pb_submit_planar.argtypes = [vp, C.c_int, C.c_int, u8p, u8p, C.c_size_t]
+    L.pb_submit_vdif.argtypes = [vp, C.c_int, C.c_int, u8p, C.c_size_t]
+    L.pb_input_dev.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.pb_process.argtypes = [vp, C.c_int, C.c_int]
+    L.pb_fetch.argtypes = [vp, C.c_int, C.c_int, C.c_int, u8p, u8p, fp, fp, fp]
+    L.pb_output_dev.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp)]
+    L.pb_coadd_local.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.pb_coadd_finish.argtypes = [vp, C.c_int, vp, C.c_int, u8p]
+    L.pb_profile.argtypes = [vp, C.c_int]
+    L.pb_get_timers.argtypes = [vp, C.POINTER(PbTimers), C.c_int]
+    L.pb_debug_fetch.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
+    L.pb_channelize_f32.argtypes = [vp, fp, C.c_int, C.c_int, fp]
+    L.pb_version.restype = C.c_char_p
+    for n in EXPORTS:
+        f = getattr(L, n)
+        if f.restype is C.c_int or n in ("pb_create", "pb_query", "pb_sync"):
+            f.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _u8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8)) if a is not None else None
+
+
+def _f32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+class PbHandle(object):
+    """One GPU's baseband->filterbank state: what process_baseband allocates once per run
+    (/root/reference/src/process_baseband.cu:578-709) plus the per-segment device work."""
+
+    def __init__(self, device=0, nant=1, nbit=8, npol=1, rfi_mode=2, taps=1, fft_backend=FFT_LDS,
+                 rows_per_seg=1024, max_seg=10, inject_frb=False, keep_ave=False, debug_keep=False):
+        L = load()
+        cfg = PbConfig()
+        L.pb_config_default(C.byref(cfg))
+        cfg.device, cfg.nant, cfg.nbit, cfg.npol = device, nant, nbit, npol
+        cfg.rfi_mode, cfg.taps, cfg.fft_backend = rfi_mode, taps, fft_backend
+        cfg.rows_per_seg, cfg.max_seg = rows_per_seg, max_seg
+        cfg.inject_frb, cfg.keep_ave, cfg.debug_keep = int(inject_frb), int(keep_ave), int(debug_keep)
+        self._L = L
+        self._h = C.c_void_p()
+        rc = L.pb_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            msg = L.pb_last_error(None).decode()
+            self._h = None
+            if rc == -22:
+                raise ValueError(msg)
+            raise PbError("pb_create failed (%d): %s" % (rc, msg))
+        self.cfg = cfg
+        s = PbSizes()
+        self._chk(L.pb_query(self._h, C.byref(s)))
+        self.sizes = s
+        self.seg_samples = int(s.seg_samples_per_pol)
+        self.trim = int(s.code_bytes_per_seg)
+        self.ave_per_seg = int(s.ave_floats_per_seg)
+        self.rows = int(s.rows_per_seg)
+        self.nblk = int(s.blocks_per_seg_pol)
+        self.nant, self.max_seg = nant, max_seg
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self._L.pb_last_error(self._h).decode()
+            if rc == -22:
+                raise ValueError(msg)
+            raise PbError("libpb_hip error %d: %s" % (rc, msg))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- input
+    def submit_planar(self, ant, seg, pol0, pol1):
+        pol0 = np.ascontiguousarray(pol0, np.uint8)
+        pol1 = np.ascontiguousarray(pol1, np.uint8)
+        if pol0.size != pol1.size:
+            raise ValueError("polarisations differ in length")
+        self._chk(self._L.pb_submit_planar(self._h, ant, seg, _u8(pol0), _u8(pol1), pol0.size))
+
+    def submit_vdif(self, ant, seg0, block):
+        block = np.ascontiguousarray(block, np.uint8)
+        self._chk(self._L.pb_submit_vdif(self._h, ant, seg0, _u8(block), block.size))
+
+    def input_dev(self, ant):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(self._L.pb_input_dev(self._h, ant, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    # ---- compute
+    def process(self, nseg, inject_now=0):
+        self._chk(self._L.pb_process(self._h, nseg, inject_now))
+
+    def sync(self):
+        self._chk(self._L.pb_sync(self._h))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self._L.pb_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    # ---- output
+    def fetch(self, ant, seg0, nseg, raw=True, kur=True, weights=False, ave=False):
+        out = {}
+        r = np.empty(nseg * self.trim, np.uint8) if raw else None
+        k = np.empty(nseg * self.trim, np.uint8) if kur else None
+        w = np.empty(nseg * self.rows, np.float32) if weights else None
+        ar = np.empty(nseg * self.ave_per_seg, np.float32) if ave else None
+        ak = np.empty(nseg * self.ave_per_seg, np.float32) if ave else None
+        self._chk(self._L.pb_fetch(self._h, ant, seg0, nseg, _u8(r), _u8(k), _f32(w), _f32(ar), _f32(ak)))
+        out.update(raw=r, kur=k, weights=w, ave_raw=ar, ave_kur=ak)
+        return out
+
+    def output_dev(self, ant, stream):
+        c, a = C.c_void_p(), C.c_void_p()
+        self._chk(self._L.pb_output_dev(self._h, ant, stream, C.byref(c), C.byref(a)))
+        return c.value, a.value
+
+    def reset_bandpass(self, ant):
+        self._chk(self._L.pb_reset_bandpass(self._h, ant))
+
+    def get_bandpass(self, ant):
+        r = np.empty((2, NCHANOUT), np.float32)
+        k = np.empty((2, NCHANOUT), np.float32)
+        self._chk(self._L.pb_get_bandpass(self._h, ant, _f32(r), _f32(k)))
+        return r, k
+
+    def set_bandpass(self, ant, raw, kur):
+        raw = np.ascontiguousarray(raw, np.float32)
+        kur = np.ascontiguousarray(kur, np.float32)
+        assert raw.size == 2 * NCHANOUT and kur.size == 2 * NCHANOUT
+        self._chk(self._L.pb_set_bandpass(self._h, ant, _f32(raw), _f32(kur)))
+
+    def coadd_local(self, nseg, d_sum_ptr, accumulate=False):
+        self._chk(self._L.pb_coadd_local(self._h, nseg, C.c_void_p(d_sum_ptr), int(accumulate)))
+
+    def coadd_finish(self, nseg, d_sum_ptr, nant_total):
+        codes = np.empty(nseg * self.trim, np.uint8)
+        self._chk(self._L.pb_coadd_finish(self._h, nseg, C.c_void_p(d_sum_ptr), nant_total, _u8(codes)))
+        return codes
+
+    def profile(self, enable=True):
+        self._chk(self._L.pb_profile(self._h, int(enable)))
+
+    def timers(self, reset=False):
+        t = PbTimers()
+        self._chk(self._L.pb_get_timers(self._h, C.byref(t), int(reset)))
+        return {n: (t.ms[i], int(t.launches[i])) for i, n in enumerate(STAGES)}
+
+    def debug_fetch(self, what, ant=0, seg=0):
+        if what in (DBG_POW, DBG_KUR, DBG_DAG):
+            a = np.empty((2, self.nblk), np.float32)
+        elif what == DBG_FLAGS:
+            a = np.empty(self.nblk, np.uint8)
+        else:
+            a = np.empty(self.rows, np.float32)
+        self._chk(self._L.pb_debug_fetch(self._h, what, ant, seg, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return a
+
+    def channelize_f32(self, x, nrows, taps=1):
+        x = np.ascontiguousarray(x, np.float32).ravel()
+        assert x.size == (nrows + taps - 1) * NFFT
+        out = np.empty((nrows, NCHAN), np.complex64)
+        self._chk(self._L.pb_channelize_f32(self._h, _f32(x), nrows, taps, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
