@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: baseband -> filterbank throughput of the HIP hot path on MI355X.
+
+Contract:  python bench.py --gpus N --steps K --warmup W
+  N = 1   one antenna, 128 MS/s dual-pol, RFI mode 2 (raw + excised streams), 8-bit out
+          (BASELINE.json configs[1]).  A *step* = one second of that antenna
+          (10 segments x 1024 FFT rows x 12500 samples x 2 pols = 256 MB of 8-bit voltages)
+          through kurtosis flagging -> channeliser -> detect/scrunch/quantise, with the raw
+          samples already resident in HBM and the filterbank bytes copied back to the host.
+  N > 1   launched one rank per GPU by torch.distributed.run; antennas shard one per GPU
+          (weak scaling) and the per-step incoherent sum of the excised fp32 planes is an
+          RCCL reduce to rank 0 over xGMI, which requantises the coadded second.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NFFT, NCHANOUT, ROWS = 12500, 4096, 1024
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def synth_second(torch, dev, seed, seg_samples, nseg, rfi_frac=0.01):
+    """genbase-style voltages on the GPU: Gaussian, mean 128.5, sigma 16.9 codes, clamped
+    (src/genbase.cu:689-708 of the reference); rfi_frac of the 500-sample blocks carry an
+    impulsive, strongly non-Gaussian burst so that the excision path does real work."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    out = []
+    for s in range(nseg):
+        pols = []
+        for p in range(2):
+            x = torch.randn(seg_samples, device=dev, generator=g) * 16.9 + 128.5
+            nblk = seg_samples // 500
+            bad = torch.rand(nblk, device=dev, generator=g) < rfi_frac
+            burst = (torch.rand(seg_samples, device=dev, generator=g) - 0.5) * 180.0
+            x = x + burst * bad.repeat_interleave(500)
+            pols.append(x.clamp_(0, 255).to(torch.uint8))
+        out.append(pols)
+    return out
+
+
+def cpu_baseline(quick=False):
+    """Reported-only CPU baseline named by north_star: the NumPy channeliser of
+    analysis/baseband.py (restated in oracle/oracle.py, pinned to the reference by
+    tests/golden) on a bounded sample of the same workload, from framed VDIF bytes to the
+    6251-channel detected plane, on this host's cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import multiprocessing as mp
+    import oracle as O
+    nseg = 2 if quick else 5                      # 0.2 / 0.5 s of one antenna, both pols
+    rows = ROWS * nseg
+    rng = np.random.default_rng(42)
+    nfr = rows * NFFT // 5000
+    raw = np.zeros((2 * nfr, 5032), np.uint8)
+    raw[:, 32:] = np.clip(rng.normal(128.5, 16.9, size=(2 * nfr, 5000)), 0, 255).astype(np.uint8)
+    raw = raw.ravel()
+    t0 = time.perf_counter()
+    v = O.vdif_get_data(raw)                      # deframe + de-interleave + float32
+    for p in range(2):
+        O.filterbank(v[p], nfft=NFFT)
+    t1 = time.perf_counter()
+    ncores = os.cpu_count() or 1
+    nsamp = rows * NFFT                           # dual-pol samples
+    one = nsamp / (t1 - t0) / 1e6
+    # all cores: FFT rows are independent -> split them over a process pool
+    chunks = [(p, i) for p in range(2) for i in range(ncores)]
+    global _CPU_V
+    _CPU_V = v
+    t2 = time.perf_counter()
+    with mp.get_context("fork").Pool(min(ncores, 32)) as pool:
+        pool.map(_cpu_chunk, [(p, i, ncores) for (p, i) in chunks])
+    t3 = time.perf_counter()
+    allc = nsamp / (t3 - t2) / 1e6
+    return {"value": round(allc, 2), "unit": "Msamp/s", "cores": min(ncores, 32), "kind": "port",
+            "value_1core": round(one, 2), "x_realtime": round(allc / 128.0, 4),
+            "sample": "%.1f s of one antenna, dual-pol: VDIF deframe + NumPy |rfft(12500)|^2 "
+                      "(analysis/baseband.py:filterbank restated); 1 core and a %d-process pool"
+                      % (nseg / 10.0, min(ncores, 32))}
+
+
+_CPU_V = None
+
+
+def _cpu_chunk(arg):
+    p, i, n = arg
+    import oracle as O
+    rows = _CPU_V.shape[1] // NFFT
+    lo, hi = rows * i // n, rows * (i + 1) // n
+    O.filterbank(_CPU_V[p, lo * NFFT:hi * NFFT], nfft=NFFT)
+    return hi - lo
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--backend", choices=["lds", "hipfft"], default="lds")
+    ap.add_argument("--rfi-mode", type=int, default=2)
+    ap.add_argument("--nbit", type=int, default=8)
+    ap.add_argument("--seg-per-step", type=int, default=10)
+    ap.add_argument("--ant-per-gpu", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    lp = importlib.import_module("vlite-fast_amd.libpb")
+    S, A = args.seg_per_step, args.ant_per_gpu
+    backend = lp.FFT_LDS if args.backend == "lds" else lp.FFT_HIPFFT
+    h = lp.PbHandle(device=local, nant=A, nbit=args.nbit, npol=1, rfi_mode=args.rfi_mode,
+                    fft_backend=backend, rows_per_seg=ROWS, max_seg=S, keep_ave=(world > 1))
+    n = h.seg_samples
+    for a in range(A):
+        sec = synth_second(torch, dev, 42 + rank * A + a, n, S)
+        torch.cuda.synchronize()
+        for s in range(S):
+            h.submit_planar_dev(a, s, sec[s][0].data_ptr(), sec[s][1].data_ptr(), n)
+        h.sync()
+        del sec
+    d_sum = torch.zeros(S * h.ave_per_seg, dtype=torch.float32, device=dev) if world > 1 else None
+    nant_total = world * A
+
+    def step():
+        h.process(S)
+        if world > 1:
+            h.coadd_local(S, d_sum.data_ptr())
+            h.sync()                      # library stream -> visible to the RCCL stream
+            dist.reduce(d_sum, dst=0, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+            if rank == 0:
+                h.coadd_finish(S, d_sum.data_ptr(), nant_total)
+        for a in range(A):
+            h.fetch(a, 0, S)              # filterbank bytes back to the host (D2H, :1370-1375)
+
+    for _ in range(args.warmup):
+        step()
+    h.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    h.timers(reset=True)
+    h.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    h.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    h.profile(False)
+    tm = h.timers(reset=True)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        samples = float(nant_total) * S * n * args.steps          # dual-pol samples
+        msamp = samples / dt / 1e6
+        nstreams = 2 if args.rfi_mode == 2 else 1
+        pbytes = nstreams * 2 * ROWS * NCHANOUT * 4                # power planes per antenna-segment
+        alg = {  # algorithmic (compulsory) HBM bytes per antenna-segment of each kernel, DESIGN.md section 5
+            "kurtosis": 2 * n + h.nblk,
+            "channelize": 2 * n + pbytes,
+            "fft": nstreams * (2 * n * 4 + 2 * ROWS * 6251 * 8),
+            "detect": (pbytes if args.backend == "lds" else nstreams * 2 * ROWS * 6251 * 8)
+                      + nstreams * (h.trim + (h.ave_per_seg * 4 if world > 1 else 0)),
+        }
+        if args.backend == "hipfft":
+            alg["kurtosis"] = 2 * n + nstreams * 2 * n * 4
+        stages = {k: v for k, v in tm.items() if v[1] > 0 and k in alg}
+        dom = max(stages, key=lambda k: stages[k][0])
+        avg_ms = stages[dom][0] / stages[dom][1]
+        per_launch = alg[dom] * S * A
+        achieved = per_launch / (avg_ms * 1e-3) / 1e9
+        chain_bps = {2: 66.09, 1: 34.04, 0: 34.04}[args.rfi_mode]  # SURVEY.md 8(d) B per dual-pol sample
+        out = {
+            "metric": "Msamp/s/antenna (dual-pol) and x real-time @128 MS/s; % HBM roofline",
+            "value": round(msamp, 1), "unit": "Msamp/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic genbase-style 8-bit Gaussian baseband (mean 128.5, sigma 16.9 codes), "
+                    "1% of 500-sample blocks with impulsive RFI; resident in HBM",
+            "config": {"workload": "configs[1]: 1 antenna/GPU, 128 MS/s dual-pol, 1 s per step "
+                                   "(10 x 100-ms segments, 2048 x 12500-pt FFT rows each), RFI mode %d, "
+                                   "%d-bit out, taps=1, %s FFT" % (args.rfi_mode, args.nbit, args.backend),
+                       "antennas": nant_total, "antennas_per_gpu": A, "segments_per_step": S,
+                       "parallelism": "antenna-per-GPU" + ("+rccl-reduce-coadd" if world > 1 else "")},
+            "msamp_per_antenna": round(msamp / nant_total, 1),
+            "x_realtime_per_antenna": round(msamp / nant_total / 128.0, 1),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                         "algorithmic_bytes_per_launch": per_launch},
+            "chain_model": {"bytes_per_sample": chain_bps,
+                            "equiv_GBps": round(msamp * 1e6 * chain_bps / 1e9, 1),
+                            "frac_of_peak": round(msamp * 1e6 * chain_bps / 1e9 / HBM_PEAK_GBS, 4),
+                            "note": "SURVEY.md 8(d) unfused-chain traffic model x measured samples/s"},
+            "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in tm.items() if v[1] > 0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    h.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,6 +123,9 @@ int pb_set_bandpass(pb_handle *h, int ant, const float *bp_raw, const float *bp_
  * src/process_baseband.cu:1116-1122 (pol-planar 8-bit samples). */
 int pb_submit_planar(pb_handle *h, int ant, int seg, const uint8_t *pol0, const uint8_t *pol1,
                      size_t nsamp_per_pol);
+/* Same from device memory (HBM-resident producer), device-to-device on the handle's stream. */
+int pb_submit_planar_dev(pb_handle *h, int ant, int seg, const void *d_pol0, const void *d_pol1,
+                         size_t nsamp_per_pol);
 /* Stage from a raw 1-s ring block of 5032-B VDIF frames (the layout writer/genbase put in
  * ring 0x40): replaces the host frame-demux loop :1015-1067 AND the H2D copies; the
  * headers are indexed on the host, payloads are gathered on the GPU.  seg0 = first of the

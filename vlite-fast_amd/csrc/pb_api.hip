@@ -8,6 +8,7 @@
 #include "pb_internal.h"
 
 static std::string g_create_err;
+static void drain_timers(pb_handle *h);
 
 #define HIPCHK(h, call)                                                                   \
     do {                                                                                  \
@@ -254,6 +255,8 @@ extern "C" void pb_destroy(pb_handle *h)
                     h->d_frb_delays, h->ft.w25, h->ft.w10, h->ft.tw2, h->ft.tw3, h->ft.post, h->ft.taps};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    drain_timers(h);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -354,6 +357,19 @@ extern "C" int pb_submit_planar(pb_handle *h, int ant, int seg, const uint8_t *p
     return PB_OK;
 }
 
+extern "C" int pb_submit_planar_dev(pb_handle *h, int ant, int seg, const void *pol0, const void *pol1, size_t nsamp)
+{
+    if (!h || !pol0 || !pol1) return PB_EINVAL;
+    if (check_ant(h, ant)) return PB_EINVAL;
+    if (seg < 0 || seg >= h->S) return fail(h, PB_EINVAL, "segment slot out of range");
+    if (nsamp != h->seg_samples) return fail(h, PB_EINVAL, "pb_submit_planar_dev: nsamp must equal seg_samples_per_pol");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    uint8_t *dst = h->d_in + (((size_t)ant * h->S + seg) * 2) * h->seg_samples;
+    HIPCHK(h, hipMemcpyAsync(dst, pol0, nsamp, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dst + h->seg_samples, pol1, nsamp, hipMemcpyDeviceToDevice, h->stream));
+    return PB_OK;
+}
+
 extern "C" int pb_submit_vdif(pb_handle *h, int ant, int seg0, const uint8_t *block, size_t nbytes)
 {
     if (!h || !block) return PB_EINVAL;
@@ -407,24 +423,55 @@ extern "C" int pb_input_dev(pb_handle *h, int ant, void **dptr, size_t *nbytes)
     return PB_OK;
 }
 
+// Per-stage device time without disturbing the stream: each stage records a pair of events
+// from a pool; pb_get_timers synchronises once and reads them all back.
+static hipEvent_t take_event(pb_handle *h)
+{
+    if (!h->ev_pool.empty()) {
+        hipEvent_t e = h->ev_pool.back();
+        h->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
 struct StageTimer {
     pb_handle *h;
     int stage;
-    StageTimer(pb_handle *h_, int s) : h(h_), stage(s)
+    hipEvent_t a, b;
+    StageTimer(pb_handle *h_, int s) : h(h_), stage(s), a(nullptr), b(nullptr)
     {
-        if (h->profile) (void)hipEventRecord(h->ev0, h->stream);
+        if (h->profile) {
+            a = take_event(h);
+            b = take_event(h);
+            (void)hipEventRecord(a, h->stream);
+        }
     }
     void stop()
     {
         if (!h->profile) return;
-        (void)hipEventRecord(h->ev1, h->stream);
-        (void)hipEventSynchronize(h->ev1);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
-        h->timers.ms[stage] += ms;
-        h->timers.launches[stage] += 1;
+        (void)hipEventRecord(b, h->stream);
+        h->pending.push_back({stage, a, b});
     }
 };
+
+static void drain_timers(pb_handle *h)
+{
+    if (h->pending.empty()) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (auto &p : h->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            h->timers.ms[p.stage] += ms;
+            h->timers.launches[p.stage] += 1;
+        }
+        h->ev_pool.push_back(p.a);
+        h->ev_pool.push_back(p.b);
+    }
+    h->pending.clear();
+}
 
 static int exec_fft(pb_handle *h, int nseg)
 {
@@ -572,6 +619,8 @@ extern "C" int pb_profile(pb_handle *h, int enable)
 extern "C" int pb_get_timers(pb_handle *h, pb_timers *out, int reset)
 {
     if (!h || !out) return PB_EINVAL;
+    (void)hipSetDevice(h->cfg.device);
+    drain_timers(h);
     *out = h->timers;
     if (reset) memset(&h->timers, 0, sizeof h->timers);
     return PB_OK;

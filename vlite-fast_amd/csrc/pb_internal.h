@@ -70,6 +70,9 @@ struct pb_handle {
     bool profile;
     hipEvent_t ev0, ev1;
     pb_timers timers;
+    struct Pending { int stage; hipEvent_t a, b; };
+    std::vector<Pending> pending;        // recorded, not yet read back
+    std::vector<hipEvent_t> ev_pool;     // free events
     std::string err;
 };
 

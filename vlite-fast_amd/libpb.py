@@ -51,7 +51,7 @@ class PbTimers(C.Structure):
 
 EXPORTS = ["pb_config_default", "pb_create", "pb_destroy", "pb_last_error", "pb_query",
            "pb_set_stream", "pb_sync", "pb_reset_bandpass", "pb_get_bandpass", "pb_set_bandpass",
-           "pb_submit_planar", "pb_submit_vdif", "pb_input_dev", "pb_process", "pb_fetch",
+           "pb_submit_planar", "pb_submit_planar_dev", "pb_submit_vdif", "pb_input_dev", "pb_process", "pb_fetch",
            "pb_output_dev", "pb_coadd_local", "pb_coadd_finish", "pb_profile", "pb_get_timers",
            "pb_debug_fetch", "pb_channelize_f32", "pb_version"]
 
@@ -82,6 +82,7 @@ def load():
     L.pb_get_bandpass.argtypes = [vp, C.c_int, fp, fp]
     L.pb_set_bandpass.argtypes = [vp, C.c_int, fp, fp]
     L.pb_submit_planar.argtypes = [vp, C.c_int, C.c_int, u8p, u8p, C.c_size_t]
+    L.pb_submit_planar_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_size_t]
     L.pb_submit_vdif.argtypes = [vp, C.c_int, C.c_int, u8p, C.c_size_t]
     L.pb_input_dev.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.pb_process.argtypes = [vp, C.c_int, C.c_int]
@@ -174,6 +175,10 @@ class PbHandle(object):
         if pol0.size != pol1.size:
             raise ValueError("polarisations differ in length")
         self._chk(self._L.pb_submit_planar(self._h, ant, seg, _u8(pol0), _u8(pol1), pol0.size))
+
+    def submit_planar_dev(self, ant, seg, d_pol0, d_pol1, nsamp):
+        """d_pol0 / d_pol1: device addresses (e.g. torch tensor .data_ptr())."""
+        self._chk(self._L.pb_submit_planar_dev(self._h, ant, seg, C.c_void_p(d_pol0), C.c_void_p(d_pol1), nsamp))
 
     def submit_vdif(self, ant, seg0, block):
         block = np.ascontiguousarray(block, np.uint8)
