@@ -16,7 +16,7 @@
 // LDS: one 6250 x float2 buffer (50 000 B) used in place: every pass reads its inputs into
 // registers, barriers, then writes.  3 workgroups per CU.
 // HBM traffic per (row, pol): 12.5 KB of samples read, 16 KB (+16 KB excised stream) of
-// power written; twiddles stay in L2.
+// power written (the excised stream's already divided by the row weight); twiddles stay in L2.
 #include "pb_internal.h"
 
 #define M_HALF 6250
@@ -213,6 +213,13 @@ __global__ __launch_bounds__(256) void k_channelize(ChanArgs a)
     const int since = inject ? (a.inject_now - 1 + seg) * a.R : 0;
 
     const bool all_bad = mask == 0x1ffffffu;
+    // row weight exactly as apply_kurtosis accumulates it: one 500/12500 per unflagged block
+    float wrow = 0.f;
+    {
+        const float inc = (float)PB_NKURTO / PB_NFFT;
+        const int good = PB_BLK_PER_FFT - __popc(mask);
+        for (int i = 0; i < good; ++i) wrow = wrow + inc;
+    }
     const bool do_raw = a.rfi_mode != 1;
     const bool do_kur = a.rfi_mode != 0;
     // stream order: raw first
@@ -251,7 +258,10 @@ __global__ __launch_bounds__(256) void k_channelize(ChanArgs a)
             }
             const float xx = X.x * X.x;
             const float yy = X.y * X.y;
-            P[c] = xx + yy;
+            const float pw = xx + yy;
+            // the excised plane carries pow / w (detect_and_normalize3 :452,:481), so that the
+            // serial bandpass recurrence downstream has no division in it
+            P[c] = is_kur ? pw / wrow : pw;
         }
     }
 }

@@ -251,19 +251,12 @@ hipError_t launch_inject_c64(pb_handle *h, int nseg, int inject_now)
 
 hipError_t launch_detect(pb_handle *h, int nseg, int)
 {
+    if (h->cfg.fft_backend != PB_FFT_HIPFFT) return launch_detect_pow(h, nseg);
     DetectArgs a;
-    const bool c64 = h->cfg.fft_backend == PB_FFT_HIPFFT;
-    if (c64) {
-        a.in[0] = h->d_Xraw;
-        a.in[1] = h->d_Xkur;
-        a.row_stride = PB_NCHAN;
-        a.chan_off = PB_CHANMIN;
-    } else {
-        a.in[0] = h->d_Praw;
-        a.in[1] = h->d_Pkur;
-        a.row_stride = PB_NCHANOUT;
-        a.chan_off = 0;
-    }
+    a.in[0] = h->d_Xraw;
+    a.in[1] = h->d_Xkur;
+    a.row_stride = PB_NCHAN;
+    a.chan_off = PB_CHANMIN;
     a.pol_stride = (size_t)h->R * a.row_stride;
     a.seg_stride = 2 * a.pol_stride;
     a.ant_stride = (size_t)h->S * a.seg_stride;
@@ -286,14 +279,8 @@ hipError_t launch_detect(pb_handle *h, int nseg, int)
     a.tscale = (float)sqrt(1. / PB_NSCRUNCH);
     const int nstreams = h->cfg.rfi_mode == 2 ? 2 : 1;
     dim3 grid(PB_NCHANOUT / 32, nstreams, h->A);
-    const bool big = (h->R % 32) == 0;
-    if (c64) {
-        if (big) k_detect<true, 32><<<grid, 64, 0, h->stream>>>(a);
-        else k_detect<true, 8><<<grid, 64, 0, h->stream>>>(a);
-    } else {
-        if (big) k_detect<false, 32><<<grid, 64, 0, h->stream>>>(a);
-        else k_detect<false, 8><<<grid, 64, 0, h->stream>>>(a);
-    }
+    if ((h->R % 32) == 0) k_detect<true, 32><<<grid, 64, 0, h->stream>>>(a);
+    else k_detect<true, 8><<<grid, 64, 0, h->stream>>>(a);
     return hipGetLastError();
 }
 

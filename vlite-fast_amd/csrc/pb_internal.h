@@ -82,6 +82,7 @@ hipError_t launch_row_weights(pb_handle *h, int nseg);
 hipError_t launch_deframe(pb_handle *h, int ant, int seg0, size_t nframes_per_thread);
 hipError_t launch_inject_c64(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_detect(pb_handle *h, int nseg, int inject_now);
+hipError_t launch_detect_pow(pb_handle *h, int nseg);
 hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_channelize_f32(pb_handle *h, const float *d_x, int nrows, int taps, float2 *d_out);
 hipError_t launch_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate);
