@@ -1,29 +1,39 @@
-// Channeliser: 8-bit unpack (+ optional 4-tap FIR window) + 12500-point real FFT + square-law
-// detect of the 4096 output channels, one workgroup per (row, pol), everything between the raw
-// bytes and the power spectrum staying in registers and LDS.
+// Channeliser: 8-bit unpack + 12500-point real FFT + square-law detect of the 4096 output
+// channels, one workgroup per (row, pol, stream), everything between the raw bytes and the
+// power spectrum staying in registers and LDS.
 //
 // Replaces, per FFT row:  convertarray (src/pb_kernels.cu:23-33), the copy/zero half of
 // apply_kurtosis (:267-287), cufftExecR2C (src/process_baseband.cu:1222-1224), inject_frb
-// (src/pb_kernels.cu:348-391) and the |X|^2 of detect_and_normalize2/3 (:416, :481).
+// (src/pb_kernels.cu:348-391), the |X|^2 of detect_and_normalize2/3 (:416, :481) and the
+// division by the row weight of detect_and_normalize3 (:452, :481).
 //
 // FFT: the 12500 real samples are packed as 6250 complex, transformed by three Stockham
 // passes of radix 25, 25, 10 and split back into the real-input spectrum.  The operation
 // order (butterfly formulas, where fmaf is used, twiddle tables) is the specification in
-// oracle/pb_oracle.c "K6"; results agree with the oracle bit for bit.  Pass r of radix 25
-// reads input r from 500-sample block r, so a flagged kurtosis block is simply a zeroed
-// butterfly input.
+// oracle/pb_oracle.c "K6"; results agree with the oracle bit for bit.  Pass-1 butterfly input
+// r comes from 500-sample kurtosis block r, so a flagged block is simply a zeroed input.
+//
+// Workgroup roles (rfi_mode 2): the "raw" workgroup of a row transforms the unflagged data and
+// writes the raw power plane -- and, when the row has no flagged block, the excised plane as
+// well (same spectrum, divided by the row weight); the "excised" workgroup exits at once in
+// that case, writes zeros if every block is flagged, and otherwise transforms the zeroed data.
 //
 // LDS: one 6250 x float2 buffer (50 000 B) used in place: every pass reads its inputs into
 // registers, barriers, then writes.  3 workgroups per CU.
-// HBM traffic per (row, pol): 12.5 KB of samples read, 16 KB (+16 KB excised stream) of
-// power written (the excised stream's already divided by the row weight); twiddles stay in L2.
+// HBM traffic per (row, pol): 12.5 KB of samples read, 16 KB + 16 KB of power written;
+// twiddles (tw2 4.9 KB, tw3 49 KB, post 49 KB) stay in L2.
+#include <cstdlib>
+#include <cstring>
+
+#include "fft_consts.h"
 #include "pb_internal.h"
 
 #define M_HALF 6250
 
-__constant__ float2 c_w25[25];   // w25^(n2*k1), [n2][k1]
-__constant__ float2 c_w10[5];    // w10^k1
-__constant__ float c_r5[4];      // cos(2pi/5), cos(4pi/5), sin(2pi/5), sin(4pi/5)
+namespace {
+constexpr float kW25[25][2] = FC_W25_INIT;
+constexpr float kW10[5][2] = FC_W10_INIT;
+}
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 w)
 {
@@ -37,7 +47,7 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 w)
 __device__ __forceinline__ void dft5(float2 v0, float2 v1, float2 v2, float2 v3, float2 v4,
                                      float2 &y0, float2 &y1, float2 &y2, float2 &y3, float2 &y4)
 {
-    const float C1 = c_r5[0], C2 = c_r5[1], S1 = c_r5[2], S2 = c_r5[3];
+    constexpr float C1 = FC_C1, C2 = FC_C2, S1 = FC_S1, S2 = FC_S2;
     const float2 t1 = make_float2(v1.x + v4.x, v1.y + v4.y);
     const float2 t2 = make_float2(v2.x + v3.x, v2.y + v3.y);
     const float2 t3 = make_float2(v1.x - v4.x, v1.y - v4.y);
@@ -61,20 +71,31 @@ __device__ __forceinline__ void dft5(float2 v0, float2 v1, float2 v2, float2 v3,
 
 __device__ __forceinline__ void dft25(float2 (&v)[25])
 {
-    float2 A[5][5];  // [n2][k1]
+    // stage 1 in place: A[n2][k1] lives in v[5*k1 + n2]
 #pragma unroll
     for (int n2 = 0; n2 < 5; ++n2) {
-        dft5(v[n2], v[5 + n2], v[10 + n2], v[15 + n2], v[20 + n2], A[n2][0], A[n2][1], A[n2][2], A[n2][3],
-             A[n2][4]);
+        float2 a0, a1, a2, a3, a4;
+        dft5(v[n2], v[5 + n2], v[10 + n2], v[15 + n2], v[20 + n2], a0, a1, a2, a3, a4);
         if (n2) {
-#pragma unroll
-            for (int k1 = 1; k1 < 5; ++k1) A[n2][k1] = cmul(A[n2][k1], c_w25[n2 * 5 + k1]);
+            a1 = cmul(a1, make_float2(kW25[n2 * 5 + 1][0], kW25[n2 * 5 + 1][1]));
+            a2 = cmul(a2, make_float2(kW25[n2 * 5 + 2][0], kW25[n2 * 5 + 2][1]));
+            a3 = cmul(a3, make_float2(kW25[n2 * 5 + 3][0], kW25[n2 * 5 + 3][1]));
+            a4 = cmul(a4, make_float2(kW25[n2 * 5 + 4][0], kW25[n2 * 5 + 4][1]));
         }
+        v[n2] = a0;
+        v[5 + n2] = a1;
+        v[10 + n2] = a2;
+        v[15 + n2] = a3;
+        v[20 + n2] = a4;
     }
+    // stage 2: for each k1 a DFT5 over n2; output k1 + 5 k2
+    float2 o[25];
 #pragma unroll
     for (int k1 = 0; k1 < 5; ++k1)
-        dft5(A[0][k1], A[1][k1], A[2][k1], A[3][k1], A[4][k1], v[k1], v[k1 + 5], v[k1 + 10], v[k1 + 15],
-             v[k1 + 20]);
+        dft5(v[5 * k1], v[5 * k1 + 1], v[5 * k1 + 2], v[5 * k1 + 3], v[5 * k1 + 4], o[k1], o[k1 + 5], o[k1 + 10],
+             o[k1 + 15], o[k1 + 20]);
+#pragma unroll
+    for (int i = 0; i < 25; ++i) v[i] = o[i];
 }
 
 __device__ __forceinline__ void dft10(float2 (&v)[10])
@@ -83,7 +104,7 @@ __device__ __forceinline__ void dft10(float2 (&v)[10])
     dft5(v[0], v[2], v[4], v[6], v[8], A0[0], A0[1], A0[2], A0[3], A0[4]);
     dft5(v[1], v[3], v[5], v[7], v[9], A1[0], A1[1], A1[2], A1[3], A1[4]);
 #pragma unroll
-    for (int k1 = 1; k1 < 5; ++k1) A1[k1] = cmul(A1[k1], c_w10[k1]);
+    for (int k1 = 1; k1 < 5; ++k1) A1[k1] = cmul(A1[k1], make_float2(kW10[k1][0], kW10[k1][1]));
 #pragma unroll
     for (int k1 = 0; k1 < 5; ++k1) {
         v[k1] = make_float2(A0[k1].x + A1[k1].x, A0[k1].y + A1[k1].y);
@@ -166,53 +187,32 @@ struct ChanArgs {
     float *Praw, *Pkur;     // [A][S][2][R][4096]
     size_t p_ant_stride;
     const float2 *tw2, *tw3, *post;
+    const float2 *postc;    // post[2155..6250], 16-byte aligned copy
     FrbParams frb;          // delays == nullptr: no injection
     int R, rfi_mode, inject_now;
 };
 
-__global__ __launch_bounds__(256) void k_channelize(ChanArgs a)
+__global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
 {
     __shared__ float2 buf[M_HALF];
-    __shared__ unsigned smask;
     const int tid = threadIdx.x;
     const int grow = blockIdx.x;  // seg * R + row
-    const int pol = blockIdx.y, ant = blockIdx.z;
+    const int pol = blockIdx.y & 1, ant = blockIdx.z;
+    // role: 0 = raw spectrum (+ excised plane when nothing is flagged), 1 = excised spectrum
+    const int role = a.rfi_mode == 2 ? (blockIdx.y >> 1) : (a.rfi_mode == 1 ? 1 : 0);
     const int seg = grow / a.R, row = grow % a.R;
 
+    unsigned mask = 0;
     if (a.rfi_mode) {
-        if (tid < 64) {
-            const uint8_t f = tid < PB_BLK_PER_FFT
-                                  ? a.flags[(size_t)ant * a.flags_ant_stride + (size_t)grow * PB_BLK_PER_FFT + tid]
-                                  : 0;
-            const unsigned long long m = __ballot(f != 0);
-            if (tid == 0) smask = (unsigned)m;
-        }
-    } else if (tid == 0) {
-        smask = 0;
-    }
-
-    const uint16_t *src = (const uint16_t *)(a.in + (size_t)ant * a.in_ant_stride +
-                                             ((size_t)seg * 2 + pol) * a.seg_samples + (size_t)row * PB_NFFT);
-    // 25 sample pairs per thread, kept packed (two 16-bit pairs per register) so that the
-    // excised pass can rebuild its inputs without a second trip to memory
-    unsigned zp[13];
-    if (tid < 250) {
+        // every lane reads the 25 flag bytes of the row (uniform addresses -> scalar loads)
+        const uint8_t *f = a.flags + (size_t)ant * a.flags_ant_stride + (size_t)grow * PB_BLK_PER_FFT;
 #pragma unroll
-        for (int r = 0; r < 25; r += 2) {
-            const unsigned lo = src[tid + 250 * r];
-            const unsigned hi = (r + 1 < 25) ? src[tid + 250 * (r + 1)] : 0u;
-            zp[r >> 1] = lo | (hi << 16);
-        }
+        for (int r = 0; r < PB_BLK_PER_FFT; ++r) mask |= (f[r] ? 1u : 0u) << r;
+        mask = __builtin_amdgcn_readfirstlane(mask);
     }
-    __syncthreads();
-    const unsigned mask = smask;
-    const size_t prow = (size_t)ant * a.p_ant_stride + (((size_t)seg * 2 + pol) * a.R + row) * PB_NCHANOUT;
-
-    // FRB injection window of this row, per channel (inject_frb :361-380)
-    const bool inject = a.frb.delays != nullptr && a.inject_now > 0;
-    const int since = inject ? (a.inject_now - 1 + seg) * a.R : 0;
-
     const bool all_bad = mask == 0x1ffffffu;
+    if (a.rfi_mode == 2 && role == 1 && mask == 0) return;  // the raw workgroup writes both planes
+
     // row weight exactly as apply_kurtosis accumulates it: one 500/12500 per unflagged block
     float wrow = 0.f;
     {
@@ -220,33 +220,72 @@ __global__ __launch_bounds__(256) void k_channelize(ChanArgs a)
         const int good = PB_BLK_PER_FFT - __popc(mask);
         for (int i = 0; i < good; ++i) wrow = wrow + inc;
     }
-    const bool do_raw = a.rfi_mode != 1;
-    const bool do_kur = a.rfi_mode != 0;
-    // stream order: raw first
-    for (int pass = 0; pass < 2; ++pass) {
-        const bool is_kur = pass == 1;
-        if (is_kur ? !do_kur : !do_raw) continue;
-        float *P = (is_kur ? a.Pkur : a.Praw) + prow;
-        if (is_kur && mask == 0 && do_raw) {
-            // no flagged block in this row: the excised spectrum IS the raw spectrum
-            // (buf still holds Z of the raw pass)
-        } else if (is_kur && all_bad) {
-            for (int c = tid; c < PB_NCHANOUT; c += 256) P[c] = 0.f;
-            continue;
-        } else {
-            float2 v[25];
+    const size_t prow = (size_t)ant * a.p_ant_stride + (((size_t)seg * 2 + pol) * a.R + row) * PB_NCHANOUT;
+    if (role == 1 && all_bad) {
+        for (int c = tid; c < PB_NCHANOUT; c += 256) a.Pkur[prow + c] = 0.f;
+        return;
+    }
+
+    // Stage the row's 12500 bytes in LDS with 16-byte loads (narrow per-lane loads are bound by
+    // the address unit, not by HBM: 2-byte loads move 128 B per wave instruction, these 1 KiB),
+    // then let every thread pick its 25 sample pairs out of LDS.  Rows are only 4-byte aligned,
+    // so load the aligned 16-byte chunks that cover the row (d_in is padded for the overhang).
+    const size_t rbyte = (size_t)ant * a.in_ant_stride + ((size_t)seg * 2 + pol) * a.seg_samples +
+                         (size_t)row * PB_NFFT;
+    const unsigned o = (unsigned)(rbyte & 15);
+    const uint4 *src16 = (const uint4 *)(a.in + (rbyte - o));
+    const int nch = (int)((o + PB_NFFT + 15) >> 4);   // <= 783
+    {
+        uint4 t[4];
 #pragma unroll
-            for (int r = 0; r < 25; ++r) {
-                const unsigned w = (zp[r >> 1] >> ((r & 1) * 16)) & 0xffffu;
-                v[r] = (is_kur && ((mask >> r) & 1u)) ? make_float2(0.f, 0.f)
-                                                      : make_float2(cvt_sample_c(w & 0xff), cvt_sample_c(w >> 8));
-            }
-            if (pass == 1 && do_raw) __syncthreads();  // raw pass's readers of buf are done
-            fft6250(v, buf, a.tw2, a.tw3, tid);
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < nch) t[i] = src16[idx];
         }
-        for (int c = tid; c < PB_NCHANOUT; c += 256) {
-            const int k = PB_CHANMIN + c;
-            float2 X = rsplit(buf, a.post, k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < nch) ((uint4 *)buf)[idx] = t[i];
+        }
+    }
+    __syncthreads();
+    float2 v[25];
+    if (tid < 250) {
+        const unsigned zmask = role == 1 ? mask : 0u;
+        const uint16_t *sb = (const uint16_t *)((const uint8_t *)buf + o);
+#pragma unroll
+        for (int r = 0; r < 25; ++r) {
+            const unsigned w = sb[tid + 250 * r];
+            v[r] = ((zmask >> r) & 1u) ? make_float2(0.f, 0.f)
+                                       : make_float2(cvt_sample_c(w & 0xff), cvt_sample_c(w >> 8));
+        }
+    }
+    __syncthreads();   // all samples are in registers before pass 1 overwrites buf
+    fft6250(v, buf, a.tw2, a.tw3, tid);
+
+    // FRB injection window of this row, per channel (inject_frb :361-380)
+    const bool inject = a.frb.delays != nullptr && a.inject_now > 0;
+    const int since = inject ? (a.inject_now - 1 + seg) * a.R : 0;
+    const bool also_kur = a.rfi_mode == 2 && role == 0 && mask == 0;
+    float *P0 = (role == 1 ? a.Pkur : a.Praw) + prow;
+    float *P1 = a.Pkur + prow;
+    // four consecutive channels per thread: 16-byte twiddle loads and 16-byte power stores
+    for (int c4 = tid * 4; c4 < PB_NCHANOUT; c4 += 1024) {
+        const float4 t01 = *(const float4 *)(a.postc + c4);
+        const float4 t23 = *(const float4 *)(a.postc + c4 + 2);
+        const float2 tw[4] = {make_float2(t01.x, t01.y), make_float2(t01.z, t01.w), make_float2(t23.x, t23.y),
+                              make_float2(t23.z, t23.w)};
+        float pw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = PB_CHANMIN + c4 + q;
+            const float2 za = buf[k == M_HALF ? 0 : k];
+            float2 zb = buf[M_HALF - k];
+            zb.y = -zb.y;
+            const float2 E = make_float2(za.x + zb.x, za.y + zb.y);
+            const float2 O = make_float2(za.x - zb.x, za.y - zb.y);
+            const float2 Pq = cmul(O, tw[q]);
+            float2 X = make_float2(0.5f * (E.x + Pq.x), 0.5f * (E.y + Pq.y));
             if (inject) {
                 const float d = a.frb.delays[k];
                 const int lo = (int)(d + 0.5) - since;
@@ -258,36 +297,46 @@ __global__ __launch_bounds__(256) void k_channelize(ChanArgs a)
             }
             const float xx = X.x * X.x;
             const float yy = X.y * X.y;
-            const float pw = xx + yy;
-            // the excised plane carries pow / w (detect_and_normalize3 :452,:481), so that the
-            // serial bandpass recurrence downstream has no division in it
-            P[c] = is_kur ? pw / wrow : pw;
+            pw[q] = xx + yy;
         }
+        // the excised plane carries pow / w (detect_and_normalize3 :452,:481), so that the
+        // serial bandpass recurrence downstream has no division in it
+        if (role == 0) *(float4 *)(P0 + c4) = make_float4(pw[0], pw[1], pw[2], pw[3]);
+        if (role == 1 || also_kur)
+            *(float4 *)((role == 1 ? P0 : P1) + c4) =
+                make_float4(pw[0] / wrow, pw[1] / wrow, pw[2] / wrow, pw[3] / wrow);
     }
+}
+
+static bool check_consts(std::string &why)
+{
+    // the literals of fft_consts.h must be what libm gives here and in the oracle
+    auto same = [](float a, double b) { float c = (float)b; return memcmp(&a, &c, 4) == 0; };
+    bool ok = same(FC_C1, cos(2.0 * M_PI / 5.0)) && same(FC_C2, cos(4.0 * M_PI / 5.0)) &&
+              same(FC_S1, sin(2.0 * M_PI / 5.0)) && same(FC_S2, sin(4.0 * M_PI / 5.0));
+    for (int x = 1; x < 5 && ok; ++x)
+        for (int y = 1; y < 5 && ok; ++y) {
+            const double ang = 2.0 * M_PI * (double)(x * y) / 25.0;
+            ok = same(kW25[x * 5 + y][0], cos(ang)) && same(kW25[x * 5 + y][1], -sin(ang));
+        }
+    for (int k = 1; k < 5 && ok; ++k) {
+        const double ang = 2.0 * M_PI * (double)k / 10.0;
+        ok = same(kW10[k][0], cos(ang)) && same(kW10[k][1], -sin(ang));
+    }
+    if (!ok) why = "fft_consts.h does not match this host's libm; rerun tools/gen_fft_consts.py";
+    return ok;
 }
 
 hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now)
 {
-    static bool consts_ready = false;
-    if (!consts_ready) {
-        float2 w25[25], w10[5];
-        for (int a = 0; a < 5; ++a)
-            for (int b = 0; b < 5; ++b) {
-                const double ang = 2.0 * M_PI * (double)(a * b) / 25.0;
-                w25[a * 5 + b] = make_float2((float)cos(ang), (float)(-sin(ang)));
-            }
-        for (int k = 0; k < 5; ++k) {
-            const double ang = 2.0 * M_PI * (double)k / 10.0;
-            w10[k] = make_float2((float)cos(ang), (float)(-sin(ang)));
-        }
-        float r5[4] = {(float)cos(2.0 * M_PI / 5.0), (float)cos(4.0 * M_PI / 5.0), (float)sin(2.0 * M_PI / 5.0),
-                       (float)sin(4.0 * M_PI / 5.0)};
-        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_w25), w25, sizeof w25);
-        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_w10), w10, sizeof w10);
-        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_r5), r5, sizeof r5);
-        if (e != hipSuccess) return e;
-        consts_ready = true;
+    static int consts_ok = -1;
+    if (consts_ok < 0) {
+        std::string why;
+        consts_ok = check_consts(why) ? 1 : 0;
+        if (!consts_ok) h->err = why;
     }
+    if (!consts_ok) return hipErrorInvalidValue;
+    if (nseg <= 0) return hipSuccess;
     ChanArgs a;
     a.in = h->d_in;
     a.in_ant_stride = (size_t)h->S * 2 * h->seg_samples;
@@ -300,6 +349,7 @@ hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now)
     a.tw2 = h->ft.tw2;
     a.tw3 = h->ft.tw3;
     a.post = h->ft.post;
+    a.postc = h->ft.postc;
     a.frb.delays = (inject_now > 0) ? h->d_frb_delays : nullptr;
     const double rate = (double)h->R * PB_NFFT * 10;
     a.frb.width = (float)(2e-3 * 10 * rate / 10 / PB_NFFT);
@@ -308,7 +358,7 @@ hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now)
     a.R = h->R;
     a.rfi_mode = h->cfg.rfi_mode;
     a.inject_now = inject_now;
-    dim3 grid((unsigned)(nseg * h->R), 2, (unsigned)h->A);
+    dim3 grid((unsigned)(nseg * h->R), h->cfg.rfi_mode == 2 ? 4 : 2, (unsigned)h->A);
     k_channelize<<<grid, 256, 0, h->stream>>>(a);
     return hipGetLastError();
 }
@@ -350,9 +400,8 @@ __global__ __launch_bounds__(256) void k_channelize_f32(const float *__restrict_
 
 hipError_t launch_channelize_f32(pb_handle *h, const float *d_x, int nrows, int taps, float2 *d_out)
 {
-    hipError_t e = launch_channelize(h, 0, 0);  // make sure the constant tables are loaded
-    (void)e;
-    (void)hipGetLastError();
+    hipError_t e = launch_channelize(h, 0, 0);  // validates the compile-time constants
+    if (e != hipSuccess) return e;
     k_channelize_f32<<<nrows, 256, 0, h->stream>>>(d_x, taps, h->ft.taps, d_out, h->ft.tw2, h->ft.tw3, h->ft.post);
     return hipGetLastError();
 }

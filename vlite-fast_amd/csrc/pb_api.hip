@@ -106,6 +106,8 @@ static int build_fft_tables(pb_handle *h)
     HIPCHK(h, hipMemcpy(t.tw2, tw2.data(), 625 * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(t.tw3, tw3.data(), 6250 * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(t.post, post.data(), PB_NCHAN * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(h, dmalloc(h, &t.postc, (size_t)PB_NCHANOUT));
+    HIPCHK(h, hipMemcpy(t.postc, post.data() + PB_CHANMIN, PB_NCHANOUT * sizeof(float2), hipMemcpyHostToDevice));
     t.c1 = (float)cos(2.0 * M_PI / 5.0);
     t.c2 = (float)cos(4.0 * M_PI / 5.0);
     t.s1 = (float)sin(2.0 * M_PI / 5.0);
@@ -143,7 +145,7 @@ static int create_impl(pb_handle *h)
     HIPCHK(h, hipEventCreate(&h->ev1));
     const size_t A = h->A, S = h->S, R = h->R;
     const size_t in_elems = A * S * 2 * h->seg_samples;
-    HIPCHK(h, dmalloc(h, &h->d_in, in_elems));
+    HIPCHK(h, dmalloc(h, &h->d_in, in_elems + 64));   // + overhang of the channeliser's 16-byte row loads
     HIPCHK(h, dmalloc(h, &h->d_flags, A * S * h->nblk_seg));
     HIPCHK(h, hipMemset(h->d_flags, 0, A * S * h->nblk_seg));
     HIPCHK(h, dmalloc(h, &h->d_wrow, A * S * R));
@@ -252,7 +254,7 @@ extern "C" void pb_destroy(pb_handle *h)
     for (auto &kv : h->plans) hipfftDestroy(kv.second);
     void *ptrs[] = {h->d_in, h->d_vdif, h->d_frame_idx, h->d_flags, h->d_wrow, h->d_stats, h->d_fraw,
                     h->d_fkur, h->d_Xraw, h->d_Xkur, h->d_Praw, h->d_Pkur, h->d_bp, h->d_codes, h->d_ave,
-                    h->d_frb_delays, h->ft.w25, h->ft.w10, h->ft.tw2, h->ft.tw3, h->ft.post, h->ft.taps};
+                    h->d_frb_delays, h->ft.w25, h->ft.w10, h->ft.tw2, h->ft.tw3, h->ft.post, h->ft.postc, h->ft.taps};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     drain_timers(h);

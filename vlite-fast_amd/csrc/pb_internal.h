@@ -32,6 +32,7 @@ struct FftTables {
     float2 *tw2;    // [25][25]  (r, k)
     float2 *tw3;    // [10][625]
     float2 *post;   // [6251]
+    float2 *postc;  // [4096] = post[2155..6250], its own 16-byte aligned allocation
     float *taps;    // [4][12500] FIR taps (taps=4) or nullptr
     float c1, c2, s1, s2;
 };
