@@ -71,6 +71,7 @@ typedef struct pb_config {
     int32_t inject_frb;     /* -i   :399-401, :711-718 */
     int32_t keep_ave;       /* also keep the fp32 pre-quantisation planes (coadd input) */
     int32_t debug_keep;     /* keep kurtosis statistics for pb_debug_fetch */
+    int32_t nsets;          /* buffer sets for batch pipelining (1 = none, 2 = double-buffered) */
 } pb_config;
 
 typedef struct pb_sizes {
@@ -146,6 +147,14 @@ int pb_process(pb_handle *h, int nseg, int inject_now);
  * weights: nseg * rows_per_seg, kur_weights as tscrunch_weights sees them. */
 int pb_fetch(pb_handle *h, int ant, int seg0, int nseg, uint8_t *raw_codes, uint8_t *kur_codes,
              float *weights, float *ave_raw, float *ave_kur);
+/* Pipelining across batches (nsets >= 2): every submit / process / fetch / debug call acts on
+ * the SELECTED buffer set.  Typical loop: select(k&1); submit; process; select((k-1)&1); fetch.
+ * Detect + D2H of one set run on a second stream while the next set's kurtosis + channeliser
+ * run on the first; the bandpass state is shared and advances in pb_process order. */
+int pb_select_set(pb_handle *h, int set);
+/* zero-copy view of the selected set's filterbank bytes in pinned host memory (valid until the
+ * next pb_process on that set): [max_seg][code_bytes_per_seg] of antenna ant, stream 0/1 */
+int pb_fetch_ptr(pb_handle *h, int ant, int stream, const uint8_t **codes);
 /* device addresses of the same outputs, [max_seg][..] each (stream 0 = raw, 1 = kur) */
 int pb_output_dev(pb_handle *h, int ant, int stream, void **codes, void **ave);
 

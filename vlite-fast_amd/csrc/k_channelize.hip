@@ -29,6 +29,9 @@
 #include "pb_internal.h"
 
 #define M_HALF 6250
+#ifndef FFT_PREFETCH
+#define FFT_PREFETCH 1   // bit 0: pass-2 twiddles, bit 1: pass-3 twiddles requested one barrier early
+#endif
 
 namespace {
 constexpr float kW25[25][2] = FC_W25_INIT;
@@ -117,6 +120,30 @@ __device__ __forceinline__ void dft10(float2 (&v)[10])
 __device__ __forceinline__ void fft6250(float2 (&v)[25], float2 *buf, const float2 *__restrict__ tw2,
                                         const float2 *__restrict__ tw3, int tid)
 {
+    // Twiddles of the next pass are requested BEFORE the barriers that precede their use, so
+    // that their L2 latency hides under this pass's arithmetic and LDS traffic.
+    const int k = tid % 25;
+    float2 t2[24];
+    float2 t3[3][9];
+    auto load_t2 = [&]() {
+        if (tid < 250) {
+#pragma unroll
+            for (int r = 1; r < 25; ++r) t2[r - 1] = tw2[r * 25 + k];
+        }
+    };
+    auto load_t3 = [&]() {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = tid + 256 * i;
+            if (j < 625) {
+#pragma unroll
+                for (int r = 1; r < 10; ++r) t3[i][r - 1] = tw3[r * 625 + j];
+            }
+        }
+    };
+#if FFT_PREFETCH & 1
+    load_t2();
+#endif
     // pass 1: R = 25, Ns = 1
     if (tid < 250) {
         dft25(v);
@@ -125,15 +152,20 @@ __device__ __forceinline__ void fft6250(float2 (&v)[25], float2 *buf, const floa
     }
     __syncthreads();
     // pass 2: R = 25, Ns = 25
-    const int k = tid % 25;
     if (tid < 250) {
 #pragma unroll
         for (int r = 0; r < 25; ++r) v[r] = buf[tid + 250 * r];
     }
     __syncthreads();
+#if !(FFT_PREFETCH & 1)
+    load_t2();
+#endif
+#if FFT_PREFETCH & 2
+    load_t3();
+#endif
     if (tid < 250) {
 #pragma unroll
-        for (int r = 1; r < 25; ++r) v[r] = cmul(v[r], tw2[r * 25 + k]);
+        for (int r = 1; r < 25; ++r) v[r] = cmul(v[r], t2[r - 1]);
         dft25(v);
         const int j0 = (tid / 25) * 625 + k;
 #pragma unroll
@@ -151,12 +183,15 @@ __device__ __forceinline__ void fft6250(float2 (&v)[25], float2 *buf, const floa
         }
     }
     __syncthreads();
+#if !(FFT_PREFETCH & 2)
+    load_t3();
+#endif
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int j = tid + 256 * i;
         if (j < 625) {
 #pragma unroll
-            for (int r = 1; r < 10; ++r) u[i][r] = cmul(u[i][r], tw3[r * 625 + j]);
+            for (int r = 1; r < 10; ++r) u[i][r] = cmul(u[i][r], t3[i][r - 1]);
             dft10(u[i]);
 #pragma unroll
             for (int r = 0; r < 10; ++r) buf[j + 625 * r] = u[i][r];
@@ -192,6 +227,9 @@ struct ChanArgs {
     int R, rfi_mode, inject_now;
 };
 
+// Three workgroups per CU (LDS 3 x 50 000 B, <= 168 VGPRs).  Measured: capping residency at two
+// to let a detect workgroup of the previous batch co-reside does not pay -- both kernels are
+// bound by VALU issue, so running them side by side only stretches each (profiles/r01 notes).
 __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
 {
     __shared__ float2 buf[M_HALF];

@@ -1,12 +1,16 @@
 // Spectral-kurtosis RFI flagging over 500-sample blocks, fused with the 8-bit unpack.
 //
-// One workgroup = one 500-sample block index, two waves = the two polarisations, because
-// the flag is the max over both pols of the D'Agostino score.  A single pass over the raw
-// bytes replaces four reference kernels:
+// One workgroup = one FFT row (12500 samples) of BOTH polarisations = 50 kurtosis blocks,
+// because the flag of a block is the max over the two pols of the D'Agostino score and the
+// weight of a row counts its unflagged blocks.  A single pass over the raw bytes replaces
 //   convertarray       src/pb_kernels.cu:23-33      (u==0 -> 0, else u/128-1)
 //   kurtosis           :35-107                      (fixed halving tree, restated for wave64)
 //   compute_dagostino  :109-134                     (double/float mix, max over pols)
-//   apply_kurtosis     :243-295                     (zero flagged blocks; weights)
+//   apply_kurtosis     :243-295                     (flags; weights; zeroing in the hipFFT path)
+// Structure: the two 12.5 KB rows are staged in LDS with 16-byte loads; each wave reduces
+// blocks (4 leaves per lane + the reference's halving tree across the wave); then 50 lanes
+// evaluate pow, kur and the double-precision D'Agostino score side by side instead of one
+// lane per block.
 // HBM traffic: 1 B/sample read; +1 B per 500 samples of flags written; in the hipFFT
 // back end additionally 4 (+4) B/sample of fp32 voltages written.
 #include "pb_internal.h"
@@ -62,85 +66,135 @@ __device__ __forceinline__ float4 cvt4(uint32_t w)
     return f;
 }
 
+#define ROW_CHUNKS 784   // 16-byte chunks covering a 12500-byte row at any 4-byte alignment
+
 template <bool WRITE_F32>
-__global__ __launch_bounds__(128) void k_kurtosis_flag(
-    const uint8_t *__restrict__ in, size_t in_ant_stride, size_t seg_samples, int blk_per_seg,
-    uint8_t *__restrict__ flags, size_t flags_ant_stride,
-    float *__restrict__ stats, size_t nblk_cap,
+__global__ __launch_bounds__(256) void k_kurtosis_row(
+    const uint8_t *__restrict__ in, size_t in_ant_stride, size_t seg_samples, int R,
+    uint8_t *__restrict__ flags, size_t flags_ant_stride, float *__restrict__ wrow_out,
+    size_t wrow_ant_stride, float *__restrict__ stats, size_t nblk_cap,
     float *__restrict__ fraw, float *__restrict__ fkur, int write_raw, DagConsts dc)
 {
-    __shared__ uint32_t sbytes[2][128];
-    __shared__ float sdag[2];
-    const int wave = threadIdx.x >> 6;  // = polarisation
-    const int lane = threadIdx.x & 63;
-    const size_t b = blockIdx.x;
+    __shared__ uint4 sraw[2][ROW_CHUNKS];
+    __shared__ float s2[50], s4[50], sdag[50];
+    __shared__ unsigned sflag[25];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int grow = blockIdx.x;  // seg * R + row
     const int ant = blockIdx.y;
-    const size_t seg = b / (size_t)blk_per_seg, bi = b % (size_t)blk_per_seg;
-    const size_t off = (seg * 2 + wave) * seg_samples + bi * PB_NKURTO;  // sample index in the antenna
-    const uint32_t *src32 = (const uint32_t *)(in + (size_t)ant * in_ant_stride + off);
+    const int seg = grow / R, row = grow % R;
 
-    const uint32_t w0 = src32[lane];
-    const uint32_t w1 = (lane + 64 < 125) ? src32[lane + 64] : 0u;
-    sbytes[wave][lane] = w0;
-    sbytes[wave][lane + 64] = w1;
-    __syncthreads();
-
-    // leaves t = lane + 64 i hold (x[t]^2, x[t+250]^2); slots 250..255 are zero
-    const uint8_t *sb = (const uint8_t *)sbytes[wave];
-    float d2[4], d4[4];
+    size_t rbyte[2];
+    unsigned off[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int t = lane + 64 * i;
-        if (t < 250) {
-            const float x0 = cvt_sample(sb[t]);
-            const float x1 = cvt_sample(sb[t + 250]);
-            const float a = x0 * x0;
-            const float tm = x1 * x1;
-            const float a2 = a * a;
-            const float t2 = tm * tm;
-            d4[i] = a2 + t2;
-            d2[i] = a + tm;
-        } else {
-            d2[i] = 0.f;
-            d4[i] = 0.f;
+    for (int pol = 0; pol < 2; ++pol) {
+        rbyte[pol] = (size_t)ant * in_ant_stride + ((size_t)seg * 2 + pol) * seg_samples + (size_t)row * PB_NFFT;
+        off[pol] = (unsigned)(rbyte[pol] & 15);
+    }
+    {
+        uint4 t[2][4];
+#pragma unroll
+        for (int pol = 0; pol < 2; ++pol) {
+            const uint4 *src16 = (const uint4 *)(in + (rbyte[pol] - off[pol]));
+            const int nch = (int)((off[pol] + PB_NFFT + 15) >> 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + 256 * i;
+                if (idx < nch) t[pol][i] = src16[idx];
+            }
+        }
+#pragma unroll
+        for (int pol = 0; pol < 2; ++pol) {
+            const int nch = (int)((off[pol] + PB_NFFT + 15) >> 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + 256 * i;
+                if (idx < nch) sraw[pol][idx] = t[pol][i];
+            }
         }
     }
-    // halving tree 128, 64 in registers, then 32..1 across the wave: d[t] += d[t+s]
-    float s2 = (d2[0] + d2[2]) + (d2[1] + d2[3]);
-    float s4 = (d4[0] + d4[2]) + (d4[1] + d4[3]);
+    __syncthreads();
+
+    // each wave reduces blocks wave, wave+4, ...: leaves t = lane + 64 i hold (x[t]^2, x[t+250]^2)
+    for (int bi = wave; bi < 50; bi += 4) {
+        const int pol = bi / 25, blk = bi % 25;
+        const uint8_t *sb = (const uint8_t *)sraw[pol] + off[pol] + blk * PB_NKURTO;
+        float d2[4], d4[4];
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        s2 = s2 + __shfl_down(s2, s);
-        s4 = s4 + __shfl_down(s4, s);
+        for (int i = 0; i < 4; ++i) {
+            const int t = lane + 64 * i;
+            if (t < 250) {
+                const float x0 = cvt_sample(sb[t]);
+                const float x1 = cvt_sample(sb[t + 250]);
+                const float a = x0 * x0;
+                const float tm = x1 * x1;
+                const float a2 = a * a;
+                const float t2 = tm * tm;
+                d4[i] = a2 + t2;
+                d2[i] = a + tm;
+            } else {
+                d2[i] = 0.f;
+                d4[i] = 0.f;
+            }
+        }
+        // halving tree 128, 64 in registers, then 32..1 across the wave: d[t] += d[t+s]
+        float r2 = (d2[0] + d2[2]) + (d2[1] + d2[3]);
+        float r4 = (d4[0] + d4[2]) + (d4[1] + d4[3]);
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            r2 = r2 + __shfl_down(r2, s);
+            r4 = r4 + __shfl_down(r4, s);
+        }
+        if (lane == 0) {
+            s2[bi] = r2;
+            s4[bi] = r4;
+        }
     }
-    if (lane == 0) {
-        const float p = s2 / PB_NKURTO;
-        const float k = s4 / PB_NKURTO / (p * p);
-        const float dg = dag_one(k, dc);
-        sdag[wave] = dg;
+    __syncthreads();
+    const size_t b0 = (size_t)grow * PB_BLK_PER_FFT;   // first block index of this row (per pol)
+    if (tid < 50) {
+        const int pol = tid / 25, blk = tid % 25;
+        const float p = s2[tid] / PB_NKURTO;
+        const float k = s4[tid] / PB_NKURTO / (p * p);
+        sdag[tid] = dag_one(k, dc);
         if (stats) {
             const size_t ab = (size_t)ant * 6 * nblk_cap;
-            stats[ab + (0 * 2 + wave) * nblk_cap + b] = p;
-            stats[ab + (1 * 2 + wave) * nblk_cap + b] = k;
+            stats[ab + (0 * 2 + pol) * nblk_cap + b0 + blk] = p;
+            stats[ab + (1 * 2 + pol) * nblk_cap + b0 + blk] = k;
         }
     }
     __syncthreads();
-    const float dmax = fmaxf(sdag[0], sdag[1]);
-    const bool bad = dmax > 3.0f;  // DAG_THRESH
-    if (lane == 0) {
-        if (stats) stats[(size_t)ant * 6 * nblk_cap + (2 * 2 + wave) * nblk_cap + b] = dmax;
-        if (wave == 0) flags[(size_t)ant * flags_ant_stride + b] = bad ? 1 : 0;
+    if (tid < 25) {
+        const float dmax = fmaxf(sdag[tid], sdag[25 + tid]);
+        const bool bad = dmax > 3.0f;  // DAG_THRESH
+        sflag[tid] = bad ? 1u : 0u;
+        flags[(size_t)ant * flags_ant_stride + b0 + tid] = bad ? 1 : 0;
+        if (stats) {
+            const size_t ab = (size_t)ant * 6 * nblk_cap;
+            stats[ab + (2 * 2 + 0) * nblk_cap + b0 + tid] = dmax;
+            stats[ab + (2 * 2 + 1) * nblk_cap + b0 + tid] = dmax;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // kur_weights after apply_kurtosis (:292): one atomicAdd of 500/12500 per unflagged block;
+        // identical addends sum to the same float in any order.  Both pols share the flag, hence
+        // kur_weights[t] == kur_weights[t + FFTS_PER_SEG].
+        const float inc = (float)PB_NKURTO / PB_NFFT;
+        float w = 0.f;
+        for (int k = 0; k < PB_BLK_PER_FFT; ++k)
+            if (!sflag[k]) w = w + inc;
+        wrow_out[(size_t)ant * wrow_ant_stride + grow] = w;
     }
     if (WRITE_F32) {
-        const size_t fo = (size_t)ant * in_ant_stride + off;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 v0 = cvt4(w0);
-        if (write_raw) ((float4 *)(fraw + fo))[lane] = v0;
-        ((float4 *)(fkur + fo))[lane] = bad ? z : v0;
-        if (lane + 64 < 125) {
-            const float4 v1 = cvt4(w1);
-            if (write_raw) ((float4 *)(fraw + fo))[lane + 64] = v1;
-            ((float4 *)(fkur + fo))[lane + 64] = bad ? z : v1;
+#pragma unroll
+        for (int pol = 0; pol < 2; ++pol) {
+            const uint32_t *sw = (const uint32_t *)((const uint8_t *)sraw[pol] + off[pol]);
+            const size_t fo = rbyte[pol];  // float index = sample index
+            for (int i = tid; i < PB_NFFT / 4; i += 256) {
+                const float4 v = cvt4(sw[i]);
+                if (write_raw) ((float4 *)(fraw + fo))[i] = v;
+                ((float4 *)(fkur + fo))[i] = sflag[i / 125] ? make_float4(0.f, 0.f, 0.f, 0.f) : v;
+            }
         }
     }
 }
@@ -167,58 +221,21 @@ hipError_t launch_kurtosis_flag(pb_handle *h, int nseg, bool write_f32)
         }
         return hipGetLastError();
     }
-    dim3 grid((unsigned)((size_t)nseg * h->nblk_seg), (unsigned)h->A);
+    dim3 grid((unsigned)(nseg * h->R), (unsigned)h->A);
+    const size_t wrow_ant = (size_t)h->S * h->R;
     if (write_f32)
-        k_kurtosis_flag<true><<<grid, 128, 0, h->stream>>>(
-            h->d_in, in_ant_stride, h->seg_samples, (int)h->nblk_seg, h->d_flags, nblk_cap,
+        k_kurtosis_row<true><<<grid, 256, 0, h->stream>>>(
+            h->d_in, in_ant_stride, h->seg_samples, h->R, h->d_flags, nblk_cap, h->d_wrow, wrow_ant,
             h->d_stats, nblk_cap, h->d_fraw, h->d_fkur, h->cfg.rfi_mode == 2 ? 1 : 0, h->dag);
     else
-        k_kurtosis_flag<false><<<grid, 128, 0, h->stream>>>(
-            h->d_in, in_ant_stride, h->seg_samples, (int)h->nblk_seg, h->d_flags, nblk_cap,
+        k_kurtosis_row<false><<<grid, 256, 0, h->stream>>>(
+            h->d_in, in_ant_stride, h->seg_samples, h->R, h->d_flags, nblk_cap, h->d_wrow, wrow_ant,
             h->d_stats, nblk_cap, nullptr, nullptr, 0, h->dag);
     return hipGetLastError();
 }
 
-// kur_weights after apply_kurtosis (src/pb_kernels.cu:292: one atomicAdd of 500/12500 per
-// unflagged block): k identical float additions give the same sum in any order, so the
-// row weight is a table lookup on the unflagged count.  The flag is shared by both pols,
-// hence kur_weights[t] == kur_weights[t + FFTS_PER_SEG].
-__constant__ float c_wtab[26];
-
-__global__ void k_row_weights(const uint8_t *__restrict__ flags, float *__restrict__ wrow,
-                              size_t rows, size_t ant_stride_rows)
-{
-    const size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    const int ant = blockIdx.y;
-    if (r >= rows) return;
-    const uint8_t *f = flags + (size_t)ant * ant_stride_rows * PB_BLK_PER_FFT + r * PB_BLK_PER_FFT;
-    int good = 0;
-#pragma unroll
-    for (int k = 0; k < PB_BLK_PER_FFT; ++k) good += f[k] ? 0 : 1;
-    wrow[(size_t)ant * ant_stride_rows + r] = c_wtab[good];
-}
-
-hipError_t launch_row_weights(pb_handle *h, int nseg)
-{
-    static bool tab_ready = false;
-    if (!tab_ready) {
-        float tab[26];
-        const float inc = (float)PB_NKURTO / PB_NFFT;
-        float w = 0.f;
-        tab[0] = 0.f;
-        for (int k = 1; k <= 25; ++k) {
-            w = w + inc;
-            tab[k] = w;
-        }
-        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_wtab), tab, sizeof tab);
-        if (e != hipSuccess) return e;
-        tab_ready = true;
-    }
-    const size_t rows = (size_t)nseg * h->R;
-    dim3 grid((unsigned)((rows + 255) / 256), (unsigned)h->A);
-    k_row_weights<<<grid, 256, 0, h->stream>>>(h->d_flags, h->d_wrow, rows, (size_t)h->S * h->R);
-    return hipGetLastError();
-}
+// row weights are produced by k_kurtosis_row itself
+hipError_t launch_row_weights(pb_handle *, int) { return hipSuccess; }
 
 // Gather 5000-byte VDIF payloads of one raw ring block into the pol-planar segment layout
 // (replaces the host loop src/process_baseband.cu:1015-1067).  idx[thread][frame] = slot of

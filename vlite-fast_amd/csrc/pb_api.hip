@@ -10,6 +10,13 @@
 static std::string g_create_err;
 static void drain_timers(pb_handle *h);
 
+static hipError_t sync_all(pb_handle *h)
+{
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && h->s_det) e = hipStreamSynchronize(h->s_det);
+    return e;
+}
+
 #define HIPCHK(h, call)                                                                   \
     do {                                                                                  \
         hipError_t e_ = (call);                                                           \
@@ -44,6 +51,7 @@ extern "C" void pb_config_default(pb_config *c)
     c->inject_frb = 0;
     c->keep_ave = 0;
     c->debug_keep = 0;
+    c->nsets = 1;
 }
 
 // D'Agostino constants with the reference's float/double evaluation (src/pb_kernels.cu:4-11)
@@ -135,6 +143,25 @@ static int build_fft_tables(pb_handle *h)
     return PB_OK;
 }
 
+static void store_set(pb_handle *h, int i)
+{
+    pb_handle::BufSet &b = h->sets[i];
+    b.d_in = h->d_in; b.d_flags = h->d_flags; b.d_codes = h->d_codes; b.h_codes = h->h_codes;
+    b.d_wrow = h->d_wrow; b.d_stats = h->d_stats; b.d_fraw = h->d_fraw; b.d_fkur = h->d_fkur;
+    b.d_Praw = h->d_Praw; b.d_Pkur = h->d_Pkur; b.d_ave = h->d_ave; b.d_Xraw = h->d_Xraw; b.d_Xkur = h->d_Xkur;
+    b.ev_chan = h->ev_chan; b.ev_det = h->ev_det; b.processed = h->processed;
+}
+
+static void load_set(pb_handle *h, int i)
+{
+    const pb_handle::BufSet &b = h->sets[i];
+    h->d_in = b.d_in; h->d_flags = b.d_flags; h->d_codes = b.d_codes; h->h_codes = b.h_codes;
+    h->d_wrow = b.d_wrow; h->d_stats = b.d_stats; h->d_fraw = b.d_fraw; h->d_fkur = b.d_fkur;
+    h->d_Praw = b.d_Praw; h->d_Pkur = b.d_Pkur; h->d_ave = b.d_ave; h->d_Xraw = b.d_Xraw; h->d_Xkur = b.d_Xkur;
+    h->ev_chan = b.ev_chan; h->ev_det = b.ev_det; h->processed = b.processed;
+    h->cur_set = i;
+}
+
 static int create_impl(pb_handle *h)
 {
     const pb_config &c = h->cfg;
@@ -143,8 +170,24 @@ static int create_impl(pb_handle *h)
     h->own_stream = true;
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
+    {
+        // detect is latency-bound and small (one workgroup per CU): give its stream the highest
+        // priority so that its workgroups slot in between the channeliser's as CUs free up
+        int lo = 0, hi = 0;
+        HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(h, hipStreamCreateWithPriority(&h->s_det, hipStreamNonBlocking, hi));
+    }
     const size_t A = h->A, S = h->S, R = h->R;
     const size_t in_elems = A * S * 2 * h->seg_samples;
+    HIPCHK(h, dmalloc(h, &h->d_bp, A * 2 * 2 * PB_NCHANOUT));
+    HIPCHK(h, hipMemset(h->d_bp, 0, A * 2 * 2 * PB_NCHANOUT * sizeof(float)));  // :702,708
+    // One buffer set per pipeline slot (cfg.nsets): while detect + D2H of one batch run on the
+    // second stream, kurtosis + channeliser of the next batch fill the other set.
+    h->sets.resize(c.nsets);
+    for (int si = 0; si < c.nsets; ++si) {
+    h->d_in = h->d_flags = h->d_codes = h->h_codes = nullptr;
+    h->d_wrow = h->d_stats = h->d_fraw = h->d_fkur = h->d_Praw = h->d_Pkur = h->d_ave = nullptr;
+    h->d_Xraw = h->d_Xkur = nullptr;
     HIPCHK(h, dmalloc(h, &h->d_in, in_elems + 64));   // + overhang of the channeliser's 16-byte row loads
     HIPCHK(h, dmalloc(h, &h->d_flags, A * S * h->nblk_seg));
     HIPCHK(h, hipMemset(h->d_flags, 0, A * S * h->nblk_seg));
@@ -167,14 +210,20 @@ static int create_impl(pb_handle *h)
         if (need_raw) HIPCHK(h, dmalloc(h, &h->d_Praw, pn));
         if (need_kur) HIPCHK(h, dmalloc(h, &h->d_Pkur, pn));
     }
-    HIPCHK(h, dmalloc(h, &h->d_bp, A * 2 * 2 * PB_NCHANOUT));
-    HIPCHK(h, hipMemset(h->d_bp, 0, A * 2 * 2 * PB_NCHANOUT * sizeof(float)));  // :702,708
     HIPCHK(h, dmalloc(h, &h->d_codes, A * 2 * S * h->trim));
     HIPCHK(h, hipMemset(h->d_codes, 0, A * 2 * S * h->trim));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_codes, A * 2 * S * h->trim, hipHostMallocDefault));
+    memset(h->h_codes, 0, A * 2 * S * h->trim);
     if (c.keep_ave) {
         HIPCHK(h, dmalloc(h, &h->d_ave, A * 2 * S * h->ave_per_seg));
         HIPCHK(h, hipMemset(h->d_ave, 0, A * 2 * S * h->ave_per_seg * sizeof(float)));
     }
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_chan, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_det, hipEventDisableTiming));
+    h->processed = 0;
+    store_set(h, si);
+    }
+    load_set(h, 0);
     if (c.inject_frb) {
         // set_frb_delays, src/pb_kernels.cu:338-346, DM 80 (src/process_baseband.cu:717)
         std::vector<float> d(PB_NCHAN);
@@ -207,6 +256,7 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
     if (c.taps == 4 && c.fft_backend != PB_FFT_LDS) return fail(nullptr, PB_EINVAL, "taps=4 needs the LDS FFT back end");
     if (!(c.fft_backend == PB_FFT_LDS || c.fft_backend == PB_FFT_HIPFFT)) return fail(nullptr, PB_EINVAL, "bad fft_backend");
     if (c.nant < 1 || c.max_seg < 1) return fail(nullptr, PB_EINVAL, "nant and max_seg must be >= 1");
+    if (c.nsets < 1 || c.nsets > 8) return fail(nullptr, PB_EINVAL, "nsets must be 1..8");
     if (c.rows_per_seg < 8 || c.rows_per_seg % PB_NSCRUNCH) return fail(nullptr, PB_EINVAL, "rows_per_seg must be a positive multiple of 8");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -232,6 +282,11 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
     h->d_wrow = h->d_stats = h->d_fraw = h->d_fkur = h->d_Praw = h->d_Pkur = h->d_bp = h->d_ave = nullptr;
     h->d_frb_delays = nullptr;
     h->d_Xraw = h->d_Xkur = nullptr;
+    h->h_codes = nullptr;
+    h->ev_chan = h->ev_det = nullptr;
+    h->processed = 0;
+    h->cur_set = 0;
+    h->s_det = nullptr;
     memset(&h->ft, 0, sizeof h->ft);
     h->profile = false;
     h->ev0 = h->ev1 = nullptr;
@@ -251,12 +306,31 @@ extern "C" void pb_destroy(pb_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->s_det) (void)hipStreamSynchronize(h->s_det);
     for (auto &kv : h->plans) hipfftDestroy(kv.second);
-    void *ptrs[] = {h->d_in, h->d_vdif, h->d_frame_idx, h->d_flags, h->d_wrow, h->d_stats, h->d_fraw,
-                    h->d_fkur, h->d_Xraw, h->d_Xkur, h->d_Praw, h->d_Pkur, h->d_bp, h->d_codes, h->d_ave,
-                    h->d_frb_delays, h->ft.w25, h->ft.w10, h->ft.tw2, h->ft.tw3, h->ft.post, h->ft.postc, h->ft.taps};
+    bool stored = false;
+    for (auto &b : h->sets) {
+        if (b.d_in == h->d_in) stored = true;
+        void *sp[] = {b.d_in, b.d_flags, b.d_codes, b.d_wrow, b.d_stats, b.d_fraw, b.d_fkur,
+                      b.d_Praw, b.d_Pkur, b.d_ave, b.d_Xraw, b.d_Xkur};
+        for (void *p : sp)
+            if (p) (void)hipFree(p);
+        if (b.h_codes) (void)hipHostFree(b.h_codes);
+        if (b.ev_chan) (void)hipEventDestroy(b.ev_chan);
+        if (b.ev_det) (void)hipEventDestroy(b.ev_det);
+    }
+    if (!stored) {  // pb_create failed half-way through a set: free the loose members
+        void *sp[] = {h->d_in, h->d_flags, h->d_codes, h->d_wrow, h->d_stats, h->d_fraw, h->d_fkur,
+                      h->d_Praw, h->d_Pkur, h->d_ave, h->d_Xraw, h->d_Xkur};
+        for (void *p : sp)
+            if (p) (void)hipFree(p);
+        if (h->h_codes) (void)hipHostFree(h->h_codes);
+    }
+    void *ptrs[] = {h->d_vdif, h->d_frame_idx, h->d_bp, h->d_frb_delays, h->ft.w25, h->ft.w10, h->ft.tw2,
+                    h->ft.tw3, h->ft.post, h->ft.postc, h->ft.taps};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->s_det) (void)hipStreamDestroy(h->s_det);
     drain_timers(h);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -284,7 +358,7 @@ extern "C" int pb_set_stream(pb_handle *h, void *s)
 {
     if (!h) return PB_EINVAL;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, sync_all(h));
     if (h->own_stream) {
         HIPCHK(h, hipStreamDestroy(h->stream));
         h->own_stream = false;
@@ -303,7 +377,7 @@ extern "C" int pb_sync(pb_handle *h)
 {
     if (!h) return PB_EINVAL;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, sync_all(h));
     return PB_OK;
 }
 
@@ -327,7 +401,7 @@ extern "C" int pb_get_bandpass(pb_handle *h, int ant, float *raw, float *kur)
     if (!h) return PB_EINVAL;
     if (check_ant(h, ant)) return PB_EINVAL;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, sync_all(h));
     const float *b = h->d_bp + (size_t)ant * 4 * PB_NCHANOUT;
     if (raw) HIPCHK(h, hipMemcpy(raw, b, 2 * PB_NCHANOUT * sizeof(float), hipMemcpyDeviceToHost));
     if (kur) HIPCHK(h, hipMemcpy(kur, b + 2 * PB_NCHANOUT, 2 * PB_NCHANOUT * sizeof(float), hipMemcpyDeviceToHost));
@@ -339,7 +413,7 @@ extern "C" int pb_set_bandpass(pb_handle *h, int ant, const float *raw, const fl
     if (!h) return PB_EINVAL;
     if (check_ant(h, ant)) return PB_EINVAL;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, sync_all(h));
     float *b = h->d_bp + (size_t)ant * 4 * PB_NCHANOUT;
     if (raw) HIPCHK(h, hipMemcpy(b, raw, 2 * PB_NCHANOUT * sizeof(float), hipMemcpyHostToDevice));
     if (kur) HIPCHK(h, hipMemcpy(b + 2 * PB_NCHANOUT, kur, 2 * PB_NCHANOUT * sizeof(float), hipMemcpyHostToDevice));
@@ -462,7 +536,7 @@ struct StageTimer {
 static void drain_timers(pb_handle *h)
 {
     if (h->pending.empty()) return;
-    (void)hipStreamSynchronize(h->stream);
+    (void)sync_all(h);
     for (auto &p : h->pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -512,6 +586,8 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
     if (!h->cfg.inject_frb) inject_now = 0;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const bool hipfft = h->cfg.fft_backend == PB_FFT_HIPFFT;
+    // this set's previous detect + D2H must have drained before its planes are refilled
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_det, 0));
     {
         StageTimer t(h, PB_ST_KURTOSIS);
         HIPCHK(h, launch_kurtosis_flag(h, nseg, hipfft));
@@ -533,11 +609,49 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         HIPCHK(h, launch_channelize(h, nseg, inject_now));
         t.stop();
     }
-    {
+    // detect + the D2H of the filterbank bytes run on the second stream, so that the next
+    // batch's kurtosis/channeliser (other buffer set) overlaps them
+    HIPCHK(h, hipEventRecord(h->ev_chan, h->stream));
+    hipStream_t s_main = h->stream;
+    h->stream = h->s_det;
+    hipError_t e = hipStreamWaitEvent(h->s_det, h->ev_chan, 0);
+    if (e == hipSuccess) {
         StageTimer t(h, PB_ST_DETECT);
-        HIPCHK(h, launch_detect(h, nseg, inject_now));
+        e = launch_detect(h, nseg, inject_now);
         t.stop();
     }
+    for (int a = 0; a < h->A && e == hipSuccess; ++a)
+        for (int st = 0; st < 2 && e == hipSuccess; ++st) {
+            if (st == 0 ? h->cfg.rfi_mode == 1 : h->cfg.rfi_mode == 0) continue;
+            const size_t o = ((size_t)a * 2 + st) * h->S * h->trim;
+            e = hipMemcpyAsync(h->h_codes + o, h->d_codes + o, (size_t)nseg * h->trim, hipMemcpyDeviceToHost,
+                               h->s_det);
+        }
+    if (e == hipSuccess) e = hipEventRecord(h->ev_det, h->s_det);
+    h->stream = s_main;
+    HIPCHK(h, e);
+    h->processed = nseg;
+    h->sets[h->cur_set].processed = nseg;
+    return PB_OK;
+}
+
+extern "C" int pb_select_set(pb_handle *h, int set)
+{
+    if (!h) return PB_EINVAL;
+    if (set < 0 || set >= (int)h->sets.size()) return fail(h, PB_EINVAL, "pb_select_set: no such buffer set");
+    store_set(h, h->cur_set);
+    load_set(h, set);
+    return PB_OK;
+}
+
+extern "C" int pb_fetch_ptr(pb_handle *h, int ant, int stream, const uint8_t **codes)
+{
+    if (!h || !codes) return PB_EINVAL;
+    if (check_ant(h, ant)) return PB_EINVAL;
+    if (stream < 0 || stream > 1) return fail(h, PB_EINVAL, "stream must be 0 or 1");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipEventSynchronize(h->ev_det));
+    *codes = h->h_codes + ((size_t)ant * 2 + stream) * h->S * h->trim;
     return PB_OK;
 }
 
@@ -549,12 +663,14 @@ extern "C" int pb_fetch(pb_handle *h, int ant, int seg0, int nseg, uint8_t *raw_
     if (seg0 < 0 || nseg < 1 || seg0 + nseg > h->S) return fail(h, PB_EINVAL, "pb_fetch: segment range");
     if ((ave_raw || ave_kur) && !h->cfg.keep_ave) return fail(h, PB_ESTATE, "pb_fetch: fp32 planes need keep_ave=1");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // the selected set's detect + asynchronous D2H (pinned mirror h_codes) have an event of
+    // their own, so fetching one set does not wait for work in flight on the other
+    HIPCHK(h, hipEventSynchronize(h->ev_det));
     const size_t S = h->S;
-    const uint8_t *c0 = h->d_codes + (((size_t)ant * 2 + 0) * S + seg0) * h->trim;
-    const uint8_t *c1 = h->d_codes + (((size_t)ant * 2 + 1) * S + seg0) * h->trim;
-    if (raw_codes) HIPCHK(h, hipMemcpy(raw_codes, c0, (size_t)nseg * h->trim, hipMemcpyDeviceToHost));
-    if (kur_codes) HIPCHK(h, hipMemcpy(kur_codes, c1, (size_t)nseg * h->trim, hipMemcpyDeviceToHost));
+    const uint8_t *c0 = h->h_codes + (((size_t)ant * 2 + 0) * S + seg0) * h->trim;
+    const uint8_t *c1 = h->h_codes + (((size_t)ant * 2 + 1) * S + seg0) * h->trim;
+    if (raw_codes) memcpy(raw_codes, c0, (size_t)nseg * h->trim);
+    if (kur_codes) memcpy(kur_codes, c1, (size_t)nseg * h->trim);
     if (ave_raw) HIPCHK(h, hipMemcpy(ave_raw, h->d_ave + (((size_t)ant * 2 + 0) * S + seg0) * h->ave_per_seg,
                                     (size_t)nseg * h->ave_per_seg * sizeof(float), hipMemcpyDeviceToHost));
     if (ave_kur) HIPCHK(h, hipMemcpy(ave_kur, h->d_ave + (((size_t)ant * 2 + 1) * S + seg0) * h->ave_per_seg,
@@ -589,6 +705,7 @@ extern "C" int pb_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumula
     if (!h->cfg.keep_ave) return fail(h, PB_ESTATE, "pb_coadd_local needs keep_ave=1");
     if (nseg < 1 || nseg > h->S) return fail(h, PB_EINVAL, "pb_coadd_local: nseg out of range");
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_det, 0));   // the fp32 planes come from detect
     StageTimer t(h, PB_ST_COADD);
     HIPCHK(h, launch_coadd_local(h, nseg, d_sum, accumulate));
     t.stop();
@@ -634,7 +751,7 @@ extern "C" int pb_debug_fetch(pb_handle *h, int what, int ant, int seg, void *ds
     if (check_ant(h, ant)) return PB_EINVAL;
     if (seg < 0 || seg >= h->S) return fail(h, PB_EINVAL, "segment out of range");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, sync_all(h));
     const size_t nb = h->nblk_seg, cap = (size_t)h->S * nb;
     if (what == PB_DBG_POW || what == PB_DBG_KUR || what == PB_DBG_DAG) {
         if (!h->d_stats) return fail(h, PB_ESTATE, "pb_debug_fetch: statistics need debug_keep=1");

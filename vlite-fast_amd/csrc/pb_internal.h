@@ -64,6 +64,22 @@ struct pb_handle {
     uint8_t *d_codes;      // [A][2 streams][S][trim]
     float *d_ave;          // [A][2 streams][S][ave_per_seg]
     float *d_frb_delays;   // [6251]
+    // --- pipeline slots: the d_* buffers above (except d_bp, d_vdif, tables) exist once per
+    // set; the members above always alias the SELECTED set (pb_select_set)
+    uint8_t *h_codes;      // pinned mirror of d_codes, filled asynchronously after detect
+    hipEvent_t ev_chan;    // channeliser of this set done (detect may start)
+    hipEvent_t ev_det;     // detect + D2H of this set done (set may be refilled / fetched)
+    int processed;         // segments of the last pb_process on this set
+    struct BufSet {
+        uint8_t *d_in, *d_flags, *d_codes, *h_codes;
+        float *d_wrow, *d_stats, *d_fraw, *d_fkur, *d_Praw, *d_Pkur, *d_ave;
+        float2 *d_Xraw, *d_Xkur;
+        hipEvent_t ev_chan, ev_det;
+        int processed;
+    };
+    std::vector<BufSet> sets;
+    int cur_set;
+    hipStream_t s_det;     // detect + D2H stream
     FftTables ft;
     DagConsts dag;
     std::map<long, hipfftHandle> plans;

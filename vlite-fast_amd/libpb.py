@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpb_hip.so")
+LIB_PATH = os.environ.get("PB_LIBPATH") or os.path.join(_HERE, "csrc", "libpb_hip.so")
 
 NFFT = 12500
 NCHAN = 6251
@@ -35,7 +35,7 @@ class PbConfig(C.Structure):
                 ("nbit", C.c_int32), ("npol", C.c_int32), ("rfi_mode", C.c_int32),
                 ("taps", C.c_int32), ("fft_backend", C.c_int32), ("rows_per_seg", C.c_int32),
                 ("max_seg", C.c_int32), ("inject_frb", C.c_int32), ("keep_ave", C.c_int32),
-                ("debug_keep", C.c_int32)]
+                ("debug_keep", C.c_int32), ("nsets", C.c_int32)]
 
 
 class PbSizes(C.Structure):
@@ -51,7 +51,7 @@ class PbTimers(C.Structure):
 
 EXPORTS = ["pb_config_default", "pb_create", "pb_destroy", "pb_last_error", "pb_query",
            "pb_set_stream", "pb_sync", "pb_reset_bandpass", "pb_get_bandpass", "pb_set_bandpass",
-           "pb_submit_planar", "pb_submit_planar_dev", "pb_submit_vdif", "pb_input_dev", "pb_process", "pb_fetch",
+           "pb_submit_planar", "pb_submit_planar_dev", "pb_submit_vdif", "pb_input_dev", "pb_process", "pb_select_set", "pb_fetch", "pb_fetch_ptr",
            "pb_output_dev", "pb_coadd_local", "pb_coadd_finish", "pb_profile", "pb_get_timers",
            "pb_debug_fetch", "pb_channelize_f32", "pb_version"]
 
@@ -87,6 +87,8 @@ def load():
     L.pb_input_dev.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.pb_process.argtypes = [vp, C.c_int, C.c_int]
     L.pb_fetch.argtypes = [vp, C.c_int, C.c_int, C.c_int, u8p, u8p, fp, fp, fp]
+    L.pb_select_set.argtypes = [vp, C.c_int]
+    L.pb_fetch_ptr.argtypes = [vp, C.c_int, C.c_int, C.POINTER(u8p)]
     L.pb_output_dev.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp)]
     L.pb_coadd_local.argtypes = [vp, C.c_int, vp, C.c_int]
     L.pb_coadd_finish.argtypes = [vp, C.c_int, vp, C.c_int, u8p]
@@ -116,7 +118,8 @@ class PbHandle(object):
     (/root/reference/src/process_baseband.cu:578-709) plus the per-segment device work."""
 
     def __init__(self, device=0, nant=1, nbit=8, npol=1, rfi_mode=2, taps=1, fft_backend=FFT_LDS,
-                 rows_per_seg=1024, max_seg=10, inject_frb=False, keep_ave=False, debug_keep=False):
+                 rows_per_seg=1024, max_seg=10, inject_frb=False, keep_ave=False, debug_keep=False,
+                 nsets=1):
         L = load()
         cfg = PbConfig()
         L.pb_config_default(C.byref(cfg))
@@ -124,6 +127,7 @@ class PbHandle(object):
         cfg.rfi_mode, cfg.taps, cfg.fft_backend = rfi_mode, taps, fft_backend
         cfg.rows_per_seg, cfg.max_seg = rows_per_seg, max_seg
         cfg.inject_frb, cfg.keep_ave, cfg.debug_keep = int(inject_frb), int(keep_ave), int(debug_keep)
+        cfg.nsets = nsets
         self._L = L
         self._h = C.c_void_p()
         rc = L.pb_create(C.byref(cfg), C.byref(self._h))
@@ -192,6 +196,15 @@ class PbHandle(object):
     # ---- compute
     def process(self, nseg, inject_now=0):
         self._chk(self._L.pb_process(self._h, nseg, inject_now))
+
+    def select_set(self, i):
+        self._chk(self._L.pb_select_set(self._h, i))
+
+    def fetch_view(self, ant, stream, nseg):
+        """Zero-copy numpy view of the selected set's codes in pinned host memory."""
+        p = C.POINTER(C.c_uint8)()
+        self._chk(self._L.pb_fetch_ptr(self._h, ant, stream, C.byref(p)))
+        return np.ctypeslib.as_array(p, shape=(nseg * self.trim,))
 
     def sync(self):
         self._chk(self._L.pb_sync(self._h))
