@@ -1,0 +1,105 @@
+"""End to end on the GPU: a genbase-style dump replayed through the process_baseband host
+(vlite-fast_amd/process_baseband.py -> libpb_hip.so) must give .fil / _kur.fil files that are
+byte-identical to the oracle's chain, including the reference's habit of dropping the last
+second; and the VDIF gather on the GPU must equal the host demux."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from helpers import libpb, make_input, oracle_run
+
+pytestmark = pytest.mark.gpu
+
+vdif = importlib.import_module("vlite-fast_amd.vdif")
+sigproc = importlib.import_module("vlite-fast_amd.sigproc")
+dada = importlib.import_module("vlite-fast_amd.dada")
+pbmod = importlib.import_module("vlite-fast_amd.process_baseband")
+
+R = 8
+SEG = 10
+FPS = R * SEG * 12500 // 5000       # frames per thread per (shortened) second = 200
+T_UNIX = 1467334800                 # 2016-07-01 01:00:00 UTC -> epoch 33, second 3600
+
+
+def _dump(path, data, station=7):
+    """data: u8 [nsec*SEG][2][R*12500] -> dump file with one observation."""
+    nsec = data.shape[0] // SEG
+    hdr = vdif.writer_header(station, 0.8718, -0.72452, "B0833-45", 58000.0, "19A-331", 33, 3600)
+    with open(path, "wb") as f:
+        f.write(vdif.ascii_header_format(hdr))
+        for s in range(nsec):
+            p0 = np.concatenate([data[s * SEG + i, 0] for i in range(SEG)])
+            p1 = np.concatenate([data[s * SEG + i, 1] for i in range(SEG)])
+            f.write(vdif.frame_block(p0, p1, 3600 + s, 33, station).tobytes())
+
+
+@pytest.mark.parametrize("nbit", [8, 2])
+def test_replay_to_fil_is_byte_exact(tmp_path, oracle, nbit):
+    nsec = 4
+    data = make_input(11, R, nsec * SEG)
+    dump = str(tmp_path / "obs.uw")
+    _dump(dump, data)
+    argv = ["-k", "40", "-K", "0", "-w", "2", "-b", str(nbit), "-P", "1", "-r", "2", "-g", "0", "-p", "0",
+            "--replay", dump, "--datadir", str(tmp_path), "--logdir", str(tmp_path / "logs"), "--no-control",
+            "--rows-per-seg", str(R), "--co-sink", str(tmp_path / "co.bin"), "--out-sink", str(tmp_path / "out.bin")]
+    args = pbmod.build_parser().parse_args(argv)
+    assert pbmod.run(args) == 0
+    fb = tmp_path / "20160701_010000_muos_ea07.fil"
+    fbk = tmp_path / "20160701_010000_muos_ea07_kur.fil"
+    assert fb.exists() and fbk.exists()
+    # oracle: the first nsec-1 seconds only (the reference drops the last one)
+    nseg = (nsec - 1) * SEG
+    res, _, _ = oracle_run(oracle, data[:nseg], R, rfi_mode=2, npol=1, nbit=nbit)
+    hdr = sigproc.sigproc_header(7, 0.8718, -0.72452, "B0833-45", 57570 + 3600 / 86400., 1, nbit)
+    assert fb.read_bytes() == hdr + b"".join(r.codes_raw.tobytes() for r in res)
+    assert fbk.read_bytes() == hdr + b"".join(r.codes_kur.tobytes() for r in res)
+    # coadd ring stand-in: header block + one write per segment of the excised stream
+    co = (tmp_path / "co.bin").read_bytes()
+    ch = vdif.ascii_header_parse(co[:4096])
+    assert ch["NCHAN"] == "4096" and ch["NBIT"] == str(nbit) and ch["SIGPROC_FILE"].endswith("_muos_ea99_kur.fil")
+    assert co[4096:] == b"".join(r.codes_kur.tobytes() for r in res)
+    # heimdall ring stand-in: nothing before 10 s have been integrated (:1482-1494)
+    assert len((tmp_path / "out.bin").read_bytes()) == 4096
+    log = next((tmp_path / "logs").glob("*_process_*.log")).read_text()
+    assert "Wrote" in log and "Proc Time" in log
+
+
+def test_out_ring_cadence_10s_then_1s(tmp_path, oracle):
+    nsec = 13
+    data = make_input(12, R, nsec * SEG, rfi=False, dropped=False)
+    dump = str(tmp_path / "obs.uw")
+    _dump(dump, data)
+    sink = dada.FileSink(str(tmp_path / "out.bin"))
+    args = pbmod.build_parser().parse_args(["-b", "8", "-w", "0", "--replay", dump, "--datadir", str(tmp_path),
+                                            "--logdir", str(tmp_path), "--no-control", "--rows-per-seg", str(R)])
+    assert pbmod.run(args, out_ring=sink) == 0
+    trim = 2 * R * 4096 // 16
+    assert sink.nwrites == [10 * SEG * trim, SEG * trim, SEG * trim]       # 12 s processed of 13
+
+
+def test_gpu_vdif_gather_equals_host_demux():
+    lp = libpb()
+    data = make_input(13, R, SEG)
+    p0 = np.concatenate([data[i, 0] for i in range(SEG)])
+    p1 = np.concatenate([data[i, 1] for i in range(SEG)])
+    blk = vdif.frame_block(p0, p1, 3600, 33, 7).reshape(-1, 5032).copy()
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(blk.shape[0])
+    perm = np.concatenate([[0], perm[perm != 0]])                  # the first frame anchors the block
+    shuffled = blk[perm].copy()
+    victim = 17
+    shuffled[victim, 3] |= 0x80                                    # invalid-data bit -> zero fill
+    ref = vdif.deframe_block(shuffled.ravel())
+    with lp.PbHandle(nbit=8, rows_per_seg=R, max_seg=SEG) as h1, lp.PbHandle(nbit=8, rows_per_seg=R, max_seg=SEG) as h2:
+        h1.submit_vdif(0, 0, shuffled.ravel())
+        h1.process(SEG)
+        a = h1.fetch(0, 0, SEG)
+        n = R * 12500
+        for s in range(SEG):
+            h2.submit_planar(0, s, ref[0, s * n:(s + 1) * n], ref[1, s * n:(s + 1) * n])
+        h2.process(SEG)
+        b = h2.fetch(0, 0, SEG)
+    assert np.array_equal(a["raw"], b["raw"]) and np.array_equal(a["kur"], b["kur"])
+    assert (ref == 0).sum() >= 5000

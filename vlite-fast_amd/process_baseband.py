@@ -1,0 +1,321 @@
+#!/usr/bin/env python3
+"""Host side of the reference's `process_baseband` executable, driving libpb_hip.so.
+
+Drop-in under scripts/start_process:50 of the reference:
+    process_baseband -k <bb_key> -K <fb_key> -w <0|1|2> -b <2|4|8> -g <gpu> -o -C <coadd_key>
+(+ optional -P 1|2  -r 0|1|2  -i  -s  -t; the legacy `-p N` of scripts/baseband_test:26 is
+accepted and ignored, as the reference's getopt string silently does).
+
+Mirrors /root/reference/src/process_baseband.cu main():
+  :358-470   option parsing (keys are hexadecimal: `-k 40` means 0x40)
+  :784-1000  per-observation set-up: ring header, first frame, file names, SIGPROC headers
+  :1015-1496 per-second loop: a second is dispatched only once a frame of the NEXT second has
+             been seen, so the last second of every observation is dropped (:1058-1064)
+  :1108-1458 ten 100-ms segments per second -> here ONE pb_submit_vdif + pb_process call
+  :1416-1441 coadd ring (one write per segment), .fil / _kur.fil
+  :1482-1494 output ring: the first write is the 10-s buffer, then one second per second
+The bandpass state lives in the PbHandle and persists across observations (:700-709).
+
+Deliberate differences: in RFI modes 0 and 1 the reference fwrite()s an
+uninitialised host pointer (:678-682 vs :1438); here the one stream that exists is written.
+"""
+import argparse
+import importlib
+import os
+import socket
+import struct
+import sys
+import time
+
+import numpy as np
+
+_pkg = __package__ or "vlite-fast_amd"
+if __package__ in (None, ""):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+vdif = importlib.import_module(_pkg + ".vdif")
+sigproc = importlib.import_module(_pkg + ".sigproc")
+dada = importlib.import_module(_pkg + ".dada")
+
+SEG_PER_SEC = 10
+MC_GROUP, MC_READER_PORT = "224.3.29.71", 20000       # src/multicast.h:14,16
+CMD_QUIT = ord("Q")                                   # src/def.h:6
+LOGDIR = "/home/vlite-master/mtk/logs"                # src/def.h:26
+
+# source allow-lists for `-w 1` (site policy of the reference, src/util.c:91-152)
+ALLOW_NAMES = ("B0329+54", "J0332+54", "B0531+21", "J0534+22", "B2319+60", "J2321+6024", "B0833-45",
+               "J0835-45", "B1237+25", "B1933+16", "R2", "R3")
+ALLOW_IDS = ("18B-405", "19A-331", "SC1046")
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog="process_baseband", add_help=False)
+    p.add_argument("-h", action="help")
+    p.add_argument("-k", dest="key_in", type=lambda s: int(s, 16), default=0x40)
+    p.add_argument("-K", dest="key_out", type=lambda s: int(s, 16), default=0)
+    p.add_argument("-C", dest="key_co", type=lambda s: int(s, 16), default=0)
+    p.add_argument("-o", dest="stdout_output", action="store_true")
+    p.add_argument("-m", dest="muos", action="store_true")   # accepted, no effect (:403-407)
+    p.add_argument("-i", dest="inject_frb", action="store_true")
+    p.add_argument("-w", dest="write_fb", type=int, default=2)
+    p.add_argument("-b", dest="nbit", type=int, default=2)
+    p.add_argument("-P", dest="npol", type=int, default=1)
+    p.add_argument("-r", dest="rfi_mode", type=int, default=2)
+    p.add_argument("-s", dest="single_pass", action="store_true")
+    p.add_argument("-t", dest="profile_pass", action="store_true")
+    p.add_argument("-g", dest="gpu_id", type=int, default=0)
+    p.add_argument("-p", dest="legacy_p", default=None)      # ignored
+    # --- extensions (not in the reference) ---
+    p.add_argument("--replay", nargs="+", default=None, help="dump file(s) instead of ring -k")
+    p.add_argument("--datadir", default=sigproc.DATADIR)
+    p.add_argument("--logdir", default=LOGDIR)
+    p.add_argument("--out-sink", default=None, help="file standing in for ring -K")
+    p.add_argument("--co-sink", default=None, help="file standing in for ring -C")
+    p.add_argument("--no-control", action="store_true", help="do not join the multicast control group")
+    p.add_argument("--fft-backend", choices=["lds", "hipfft"], default="lds")
+    p.add_argument("--taps", type=int, default=1)
+    p.add_argument("--rows-per-seg", type=int, default=1024, help="test hook: shorter segments")
+    return p
+
+
+def validate(args):
+    if args.nbit not in (2, 4, 8):
+        raise SystemExit("Unsupported NBIT!")
+    if args.rfi_mode not in (0, 1, 2):
+        raise SystemExit("Unsupported RFI mode!")
+    if args.npol not in (1, 2):
+        raise SystemExit("Unsupported npol!")
+    if args.rows_per_seg == 1024 and args.gpu_id not in (0, 1, 2, 3, 4, 5, 6, 7):
+        raise SystemExit("Unsupported GPU id!")
+
+
+class Log(object):
+    """multilog stand-in: timestamped lines to the per-process log file and optionally stdout."""
+
+    def __init__(self, logdir, to_stdout):
+        self.fps = []
+        stamp = time.strftime("%Y%m%d_%H%M%S", time.gmtime())
+        path = os.path.join(logdir, "%s_%s_process_%06d.log" % (stamp, socket.gethostname(), os.getpid()))
+        try:
+            os.makedirs(logdir, exist_ok=True)
+            self.fps.append(open(path, "w"))
+        except OSError:
+            pass
+        if to_stdout:
+            self.fps.append(sys.stdout)
+
+    def __call__(self, level, msg):
+        line = "[%s] %s%s" % (time.strftime("%Y-%m-%d-%H:%M:%S", time.gmtime()),
+                              "ERR: " if level == "ERR" else "", msg)
+        for fp in self.fps:
+            fp.write(line if line.endswith("\n") else line + "\n")
+            fp.flush()
+
+
+def open_control_socket():
+    """Non-blocking membership of 224.3.29.71:20000 (src/utils.c:619, process_baseband.cu:764)."""
+    try:
+        s = socket.socket(socket.AF_INET, socket.SOCK_DGRAM, socket.IPPROTO_UDP)
+        s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        s.bind(("", MC_READER_PORT))
+        mreq = struct.pack("4sl", socket.inet_aton(MC_GROUP), socket.INADDR_ANY)
+        s.setsockopt(socket.IPPROTO_IP, socket.IP_ADD_MEMBERSHIP, mreq)
+        s.setblocking(False)
+        return s
+    except OSError:
+        return None
+
+
+def test_for_cmd(sock, cmd):
+    """src/utils.c:174-186: one non-blocking read of up to 32 bytes, any byte equal to cmd."""
+    if sock is None:
+        return False
+    try:
+        buf = sock.recv(32)
+    except (BlockingIOError, OSError):
+        return False
+    return cmd in buf
+
+
+def source_allowed(hdr):
+    name = hdr.get("NAME", "")
+    if any(n in name for n in ALLOW_NAMES):
+        return True
+    return any(i in hdr.get("DATAID", "") for i in ALLOW_IDS)
+
+
+def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None):
+    """Process observations until the input ring is exhausted or CMD_QUIT.  Returns the exit
+    status of the reference (0, or 1 after a >1 s data skip)."""
+    validate(args)
+    lp = importlib.import_module(_pkg + ".libpb")
+    log = Log(args.logdir, args.stdout_output)
+    log("INFO", "[PROCESS_BASEBAND] invoked with: \n%s" % " ".join(sys.argv))
+    R = args.rows_per_seg
+    frames_per_sec = R * SEG_PER_SEC * 12500 // vdif.VD_DAT     # per thread; 25600 at R = 1024
+    sec_bytes = 2 * frames_per_sec * vdif.VD_FRM                # 257 638 400 at R = 1024
+    if in_ring is None:
+        in_ring = dada.FileRing(args.replay) if args.replay else dada.open_ring(args.key_in)
+    if out_ring is None and (args.out_sink or args.key_out):
+        out_ring = dada.FileSink(args.out_sink) if args.out_sink else dada.open_ring(args.key_out, "w")
+    if co_ring is None and (args.co_sink or args.key_co):
+        co_ring = dada.FileSink(args.co_sink) if args.co_sink else dada.open_ring(args.key_co, "w")
+    own_handle = handle is None
+    if handle is None:
+        handle = lp.PbHandle(device=args.gpu_id, nant=1, nbit=args.nbit, npol=args.npol, rfi_mode=args.rfi_mode,
+                             taps=args.taps, fft_backend=lp.FFT_LDS if args.fft_backend == "lds" else lp.FFT_HIPFFT,
+                             rows_per_seg=R, max_seg=SEG_PER_SEC, inject_frb=args.inject_frb)
+    trim = handle.trim
+    ctl = None if args.no_control else open_control_socket()
+    tsamp = 12500.0 / 128e6 * 8
+    exit_status, quit_ = 0, False
+    written_files = []
+
+    while not quit_:
+        if test_for_cmd(ctl, CMD_QUIT):
+            break
+        log("INFO", "Waiting for DADA header.")
+        raw_hdr = in_ring.next_header()
+        if raw_hdr is None:
+            log("INFO", "Input ring closed.  Exiting.")
+            break
+        t_obs = time.time()
+        hdr = vdif.ascii_header_parse(raw_hdr)
+        log("INFO", "Beginning new observation.")
+        block = np.empty(sec_bytes, np.uint8)
+        first = in_ring.read(vdif.VD_FRM)
+        if len(first) != vdif.VD_FRM:
+            log("ERR", "Problem reading first bloody frame!  Bailing.")
+            return 1
+        vh = vdif.unpack_header(first)
+        if vh["frame"] != 0 and vh["thread"] != 0:      # sic: `&&` in the reference (:845)
+            log("ERR", "Incoming data were not aligned!")
+            return 1
+        station = int(hdr.get("STATIONID", 0))
+        t_unix = vdif.vdif_to_unixepoch(vh)
+        fb, fb_kur, cofb, cofb_kur = sigproc.fb_names(t_unix, station, args.datadir)
+        heimdall_file = fb_kur if args.rfi_mode else fb
+        coheimdall_file = cofb_kur if args.rfi_mode else cofb
+        write_to_null = args.write_fb == 0
+        if args.write_fb == 1:
+            if source_allowed(hdr):
+                log("INFO", "Source %s matches target list, recording filterbank data." % hdr.get("NAME", ""))
+            else:
+                write_to_null = True
+                log("INFO", "Source %s not on target list, disabling filterbank data." % hdr.get("NAME", ""))
+        if write_to_null:
+            log("INFO", "Filterbank output disabled.  Would have written to %s." % fb)
+            fb = fb_kur = os.devnull
+        fb_fp, fb_kur_fp = None, None
+        if args.rfi_mode in (0, 2):
+            fb_fp = open(fb, "wb")
+            log("INFO", "Writing no-RFI-excision filterbanks to %s." % fb)
+        else:
+            fb_fp = open(fb_kur, "wb")
+            log("INFO", "Writing RFI-excision filterbanks to %s." % fb_kur)
+        if args.rfi_mode == 2:
+            fb_kur_fp = open(fb_kur, "wb")
+            log("INFO", "Writing RFI-excision filterbanks to %s." % fb_kur)
+        mjd, mjd_sec = vdif.frame_mjd(vh), vdif.frame_mjd_sec(vh)
+        if out_ring is not None:
+            out_ring.write_header(vdif.ascii_header_format(sigproc.psrdada_out_header(
+                hdr, vh, args.npol, args.nbit, heimdall_file, t_unix, mjd, mjd_sec)))
+        if co_ring is not None:
+            co_ring.write_header(vdif.ascii_header_format(sigproc.psrdada_out_header(
+                hdr, vh, args.npol, args.nbit, coheimdall_file, t_unix, mjd, mjd_sec)))
+        sp_hdr = sigproc.sigproc_header(station, float(hdr.get("RA", 0)), float(hdr.get("DEC", 0)),
+                                        hdr.get("NAME", ""), vdif.frame_dmjd(vh, frames_per_sec), args.npol, args.nbit)
+        fb_fp.write(sp_hdr)
+        if fb_kur_fp:
+            fb_kur_fp.write(sp_hdr)
+
+        current_sec = vh["second"]
+        log("INFO", "Starting sec=%d, thread=%d" % (current_sec, vh["thread"]))
+        integrated_sec, fb_bytes = 0, 0
+        out_buf = []           # 10-s buffer of the stream heimdall gets (:691-697)
+        t_rt = time.time()
+        pending = first        # first frame of the second being assembled
+        while True:
+            # assemble one second: the pending frame + the rest of the block
+            block[:vdif.VD_FRM] = np.frombuffer(pending, np.uint8)
+            rest = in_ring.read(sec_bytes - vdif.VD_FRM)
+            if len(rest) != sec_bytes - vdif.VD_FRM:
+                if len(rest) % vdif.VD_FRM:
+                    log("INFO", "Packet size=%d, expected %d.  Aborting this observation."
+                        % (len(rest) % vdif.VD_FRM, vdif.VD_FRM))
+                break                                   # partial final second: dropped
+            block[vdif.VD_FRM:] = np.frombuffer(rest, np.uint8)
+            # a second is dispatched only when a frame of the next second has arrived
+            nxt = in_ring.read(vdif.VD_FRM)
+            if len(nxt) != vdif.VD_FRM:
+                break                                   # end of data: the last second is dropped
+            nh = vdif.unpack_header(nxt)
+            if nh["second"] - current_sec > 1:
+                log("ERR", "Major data skip!  (%d vs. %d; thread = %d) Aborting this observation."
+                    % (nh["second"], current_sec, nh["thread"]))
+                exit_status, quit_ = 1, True
+                break
+            if test_for_cmd(ctl, CMD_QUIT):
+                log("INFO", "Received CMD_QUIT, indicating data taking is ceasing.  Exiting.")
+                quit_ = True
+                break
+            inject_now = 1 if (args.inject_frb and current_sec % 60 == 0) else 0
+            if inject_now:
+                log("INFO", "Injecting an FRB with integrated = %.2f!!!." % float(integrated_sec))
+            handle.submit_vdif(0, 0, block)
+            handle.process(SEG_PER_SEC, inject_now)
+            out = handle.fetch(0, 0, SEG_PER_SEC, raw=args.rfi_mode != 1, kur=args.rfi_mode != 0)
+            main_codes = out["raw"] if args.rfi_mode != 1 else out["kur"]
+            heim_codes = out["kur"] if args.rfi_mode != 0 else out["raw"]
+            for iseg in range(SEG_PER_SEC):
+                sl = slice(iseg * trim, (iseg + 1) * trim)
+                if co_ring is not None:
+                    co_ring.write(heim_codes[sl])
+                fb_fp.write(main_codes[sl].tobytes())
+                if fb_kur_fp:
+                    fb_kur_fp.write(out["kur"][sl].tobytes())
+                fb_bytes += trim
+            out_buf.append(heim_codes.copy())
+            integrated_sec += 1
+            if integrated_sec % 10 == 0:
+                lag = (time.time() - t_rt) - 10.0 * (R / 1024.0)
+                if lag > 0.5:
+                    log("ERR", "Measured time exceeding integrated time: lag %.2f s" % lag)
+                t_rt = time.time()
+            if integrated_sec >= 10 and out_ring is not None:
+                if integrated_sec == 10:
+                    out_ring.write(np.concatenate(out_buf))      # the full 10-s buffer
+                else:
+                    out_ring.write(out_buf[-1])                  # then 1 s at a time
+            if len(out_buf) > 10:
+                out_buf.pop(0)
+            current_sec = nh["second"]
+            pending = nxt
+
+        if out_ring is not None:
+            out_ring.end_of_data()
+        if co_ring is not None:
+            co_ring.end_of_data()
+        if hasattr(in_ring, "finish_observation"):
+            in_ring.finish_observation()
+        fb_fp.close()
+        if fb_kur_fp:
+            fb_kur_fp.close()
+        nsamp = fb_bytes * (8 // args.nbit) // 4096
+        log("INFO", "Wrote %.2f MB (%.2f s) to %s" % (fb_bytes * 1e-6, nsamp * tsamp, fb))
+        log("INFO", "Proc Time...%.3f" % (time.time() - t_obs))
+        written_files.append((fb, fb_kur if args.rfi_mode == 2 else None))
+        if args.profile_pass or args.single_pass:
+            break
+    if own_handle:
+        handle.close()
+    run.last_files = written_files
+    return exit_status
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    sys.exit(run(args))
+
+
+if __name__ == "__main__":
+    main()
