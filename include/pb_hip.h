@@ -142,6 +142,11 @@ int pb_input_dev(pb_handle *h, int ant, void **dptr, size_t *nbytes);
  * call (0 = none); it is advanced per segment internally. */
 int pb_process(pb_handle *h, int nseg, int inject_now);
 
+/* Parameters of the injected test FRB (needs inject_frb=1).  Reference: DM 80, 2 ms, x1.05,
+ * compile-time (src/process_baseband.cu:717,1238-1239); generalised so that BASELINE config 3
+ * (DM 500) can be synthesised.  width_rows < 0 selects the reference's 2 ms. */
+int pb_set_frb_params(pb_handle *h, float dm, float width_rows, float amp);
+
 /* The D2H copies at :1370-1375.  Any pointer may be NULL.  raw_codes / kur_codes:
  * nseg * code_bytes_per_seg; ave_*: nseg * ave_floats_per_seg (needs keep_ave);
  * weights: nseg * rows_per_seg, kur_weights as tscrunch_weights sees them. */

@@ -389,9 +389,8 @@ hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now)
     a.post = h->ft.post;
     a.postc = h->ft.postc;
     a.frb.delays = (inject_now > 0) ? h->d_frb_delays : nullptr;
-    const double rate = (double)h->R * PB_NFFT * 10;
-    a.frb.width = (float)(2e-3 * 10 * rate / 10 / PB_NFFT);
-    a.frb.amp = 1.05f;
+    a.frb.width = h->frb_width;
+    a.frb.amp = h->frb_amp;
     a.frb.since = 0;
     a.R = h->R;
     a.rfi_mode = h->cfg.rfi_mode;

@@ -236,16 +236,14 @@ hipError_t launch_inject_c64(pb_handle *h, int nseg, int inject_now)
     const size_t pol_stride = (size_t)h->R * PB_NCHAN;
     const size_t seg_stride = 2 * pol_stride;
     const size_t ant_stride = (size_t)h->S * seg_stride;
-    // frb_width = 2e-3*SEG_PER_SEC*FFTS_PER_SEG, macro expanded left to right (:1238)
-    const double rate = (double)h->R * PB_NFFT * 10;
-    const float width = (float)(2e-3 * 10 * rate / 10 / PB_NFFT);
+    const float width = h->frb_width;
     dim3 grid((PB_NCHANOUT + 255) / 256, nseg, h->A);
     if (h->cfg.rfi_mode != 1)
         k_inject_c64<<<grid, 256, 0, h->stream>>>(h->d_Xraw, ant_stride, seg_stride, pol_stride,
-                                                  h->d_frb_delays, inject_now, width, 1.05f, h->R);
+                                                  h->d_frb_delays, inject_now, width, h->frb_amp, h->R);
     if (h->cfg.rfi_mode != 0)
         k_inject_c64<<<grid, 256, 0, h->stream>>>(h->d_Xkur, ant_stride, seg_stride, pol_stride,
-                                                  h->d_frb_delays, inject_now, width, 1.05f, h->R);
+                                                  h->d_frb_delays, inject_now, width, h->frb_amp, h->R);
     return hipGetLastError();
 }
 

@@ -162,6 +162,24 @@ static void load_set(pb_handle *h, int i)
     h->cur_set = i;
 }
 
+// set_frb_delays, src/pb_kernels.cu:338-346; width_rows < 0 selects the reference's 2 ms
+// (frb_width = 2e-3*SEG_PER_SEC*FFTS_PER_SEG with the macro expanded left to right, :1238)
+static int set_frb(pb_handle *h, float dm, float width_rows, float amp)
+{
+    std::vector<float> d(PB_NCHAN);
+    const double rate = (double)h->R * PB_NFFT * 10;
+    for (int i = 0; i < PB_NCHAN; ++i) {
+        const double freq = 0.384 - (i * 0.064) / PB_NCHAN;
+        const double scale = 4.15e-3 * dm * 10 * rate / 10 / PB_NFFT;
+        d[i] = (float)(scale / (freq * freq) - scale / (0.384 * 0.384));
+    }
+    if (!h->d_frb_delays) HIPCHK(h, dmalloc(h, &h->d_frb_delays, (size_t)PB_NCHAN));
+    HIPCHK(h, hipMemcpy(h->d_frb_delays, d.data(), PB_NCHAN * sizeof(float), hipMemcpyHostToDevice));
+    h->frb_width = width_rows < 0 ? (float)(2e-3 * 10 * rate / 10 / PB_NFFT) : width_rows;
+    h->frb_amp = amp;
+    return PB_OK;
+}
+
 static int create_impl(pb_handle *h)
 {
     const pb_config &c = h->cfg;
@@ -225,17 +243,9 @@ static int create_impl(pb_handle *h)
     }
     load_set(h, 0);
     if (c.inject_frb) {
-        // set_frb_delays, src/pb_kernels.cu:338-346, DM 80 (src/process_baseband.cu:717)
-        std::vector<float> d(PB_NCHAN);
-        const float dm = 80;
-        for (int i = 0; i < PB_NCHAN; ++i) {
-            const double freq = 0.384 - (i * 0.064) / PB_NCHAN;
-            const double rate = (double)R * PB_NFFT * 10;
-            const double scale = 4.15e-3 * dm * 10 * rate / 10 / PB_NFFT;
-            d[i] = (float)(scale / (freq * freq) - scale / (0.384 * 0.384));
-        }
-        HIPCHK(h, dmalloc(h, &h->d_frb_delays, (size_t)PB_NCHAN));
-        HIPCHK(h, hipMemcpy(h->d_frb_delays, d.data(), PB_NCHAN * sizeof(float), hipMemcpyHostToDevice));
+        // DM of 80, 2 ms, amplitude 1.05: src/process_baseband.cu:717,1238-1239
+        int rc = set_frb(h, 80.f, -1.f, 1.05f);
+        if (rc) return rc;
     }
     int rc = build_fft_tables(h);
     if (rc) return rc;
@@ -281,6 +291,8 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
     h->vdif_cap = 0;
     h->d_wrow = h->d_stats = h->d_fraw = h->d_fkur = h->d_Praw = h->d_Pkur = h->d_bp = h->d_ave = nullptr;
     h->d_frb_delays = nullptr;
+    h->frb_width = 0.f;
+    h->frb_amp = 1.f;
     h->d_Xraw = h->d_Xkur = nullptr;
     h->h_codes = nullptr;
     h->ev_chan = h->ev_det = nullptr;
@@ -633,6 +645,16 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
     h->processed = nseg;
     h->sets[h->cur_set].processed = nseg;
     return PB_OK;
+}
+
+extern "C" int pb_set_frb_params(pb_handle *h, float dm, float width_rows, float amp)
+{
+    if (!h) return PB_EINVAL;
+    if (!h->cfg.inject_frb) return fail(h, PB_ESTATE, "pb_set_frb_params needs inject_frb=1");
+    if (!(dm >= 0) || !(amp > 0)) return fail(h, PB_EINVAL, "pb_set_frb_params: bad dm or amp");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, sync_all(h));
+    return set_frb(h, dm, width_rows, amp);
 }
 
 extern "C" int pb_select_set(pb_handle *h, int set)

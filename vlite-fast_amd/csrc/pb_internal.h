@@ -64,6 +64,7 @@ struct pb_handle {
     uint8_t *d_codes;      // [A][2 streams][S][trim]
     float *d_ave;          // [A][2 streams][S][ave_per_seg]
     float *d_frb_delays;   // [6251]
+    float frb_width, frb_amp;   // inject_frb parameters (rows, amplitude factor)
     // --- pipeline slots: the d_* buffers above (except d_bp, d_vdif, tables) exist once per
     // set; the members above always alias the SELECTED set (pb_select_set)
     uint8_t *h_codes;      // pinned mirror of d_codes, filled asynchronously after detect

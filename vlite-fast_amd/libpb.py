@@ -51,7 +51,7 @@ class PbTimers(C.Structure):
 
 EXPORTS = ["pb_config_default", "pb_create", "pb_destroy", "pb_last_error", "pb_query",
            "pb_set_stream", "pb_sync", "pb_reset_bandpass", "pb_get_bandpass", "pb_set_bandpass",
-           "pb_submit_planar", "pb_submit_planar_dev", "pb_submit_vdif", "pb_input_dev", "pb_process", "pb_select_set", "pb_fetch", "pb_fetch_ptr",
+           "pb_submit_planar", "pb_submit_planar_dev", "pb_submit_vdif", "pb_input_dev", "pb_process", "pb_set_frb_params", "pb_select_set", "pb_fetch", "pb_fetch_ptr",
            "pb_output_dev", "pb_coadd_local", "pb_coadd_finish", "pb_profile", "pb_get_timers",
            "pb_debug_fetch", "pb_channelize_f32", "pb_version"]
 
@@ -66,6 +66,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PbError("%s not found: build it with `make -C vlite-fast_amd/csrc`; "
                       "there is no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64 (soname
+    # libamdhip64.so.7) but link it by file name.  If torch is imported AFTER this library has
+    # pulled in /opt/rocm's copy, the loader maps a second runtime and torch then sees no GPU.
+    # Importing torch first makes both resolve to the same (torch's) runtime.
+    if os.environ.get("PB_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, u8p, fp = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_float)
     L.pb_config_default.argtypes = [C.POINTER(PbConfig)]
@@ -87,6 +96,7 @@ def load():
     L.pb_input_dev.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.pb_process.argtypes = [vp, C.c_int, C.c_int]
     L.pb_fetch.argtypes = [vp, C.c_int, C.c_int, C.c_int, u8p, u8p, fp, fp, fp]
+    L.pb_set_frb_params.argtypes = [vp, C.c_float, C.c_float, C.c_float]
     L.pb_select_set.argtypes = [vp, C.c_int]
     L.pb_fetch_ptr.argtypes = [vp, C.c_int, C.c_int, C.POINTER(u8p)]
     L.pb_output_dev.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp)]
@@ -196,6 +206,9 @@ class PbHandle(object):
     # ---- compute
     def process(self, nseg, inject_now=0):
         self._chk(self._L.pb_process(self._h, nseg, inject_now))
+
+    def set_frb_params(self, dm=80.0, width_rows=-1.0, amp=1.05):
+        self._chk(self._L.pb_set_frb_params(self._h, dm, width_rows, amp))
 
     def select_set(self, i):
         self._chk(self._L.pb_select_set(self._h, i))
