@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<tag>/ (tools/profile_gpu.sh) into the committed summaries under profiles/:
+  profiles/<round>_<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats, our kernels only
+  profiles/<round>_<tag>_traffic.json       per-kernel HBM bytes per launch from the PMC passes:
+      read  = FETCH_SIZE x 1024 x 2   (gfx950: FETCH_SIZE reports half the bytes of a wide coalesced
+                                       stream, MI355X_MICROARCH.md "HBM")
+      write = WRITE_SIZE x 1024
+bench.py reads the traffic file for its `roofline.traffic` field."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    tag, rnd = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r01")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(root, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
+    rows = list(csv.DictReader(open(stats)))
+    keep = [r for r in rows if r["Name"].lstrip("void ").startswith("k_")]
+    with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (rnd, tag)), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(keep)
+    traffic = {}
+    for what, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        f = glob.glob(os.path.join(src, what, "*", "*counter_collection.csv"))[0]
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == ctr and r["Kernel_Name"].lstrip("void ").startswith("k_"):
+                acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            v = sorted(v)[len(v) // 4:]          # drop warm-up outliers
+            traffic.setdefault(k, {})[ctr + "_KiB_per_launch"] = sum(v) / len(v)
+    for k, t in traffic.items():
+        t["read_bytes_per_launch"] = t.get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024 * 2
+        t["write_bytes_per_launch"] = t.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024
+        t["hbm_bytes_per_launch"] = t["read_bytes_per_launch"] + t["write_bytes_per_launch"]
+    bench = json.loads(open(os.path.join(src, "bench_stats.json")).read().strip().splitlines()[-1])
+    out = {"tag": tag, "bench_config": bench["config"], "bench_under_profiler": {k: bench[k] for k in ("value", "ms_per_step", "stage_ms_per_step")},
+           "kernels": traffic,
+           "note": "read = FETCH_SIZE*1024*2 (gfx950 correction), write = WRITE_SIZE*1024; separate --pmc passes"}
+    json.dump(out, open(os.path.join(dst, "%s_%s_traffic.json" % (rnd, tag)), "w"), indent=1)
+    for k, t in traffic.items():
+        print("%-40s read %8.1f MB  write %8.1f MB per launch" % (k[:40], t["read_bytes_per_launch"] / 1e6, t["write_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()

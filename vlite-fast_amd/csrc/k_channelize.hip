@@ -16,7 +16,8 @@
 // Workgroup roles (rfi_mode 2): the "raw" workgroup of a row transforms the unflagged data and
 // writes the raw power plane -- and, when the row has no flagged block, the excised plane as
 // well (same spectrum, divided by the row weight); the "excised" workgroup exits at once in
-// that case, writes zeros if every block is flagged, and otherwise transforms the zeroed data.
+// that case, writes +inf ("no data") if every block is flagged, and otherwise transforms the
+// zeroed data.
 //
 // LDS: one 6250 x float2 buffer (50 000 B) used in place: every pass reads its inputs into
 // registers, barriers, then writes.  3 workgroups per CU.
@@ -260,7 +261,10 @@ __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
     }
     const size_t prow = (size_t)ant * a.p_ant_stride + (((size_t)seg * 2 + pol) * a.R + row) * PB_NCHANOUT;
     if (role == 1 && all_bad) {
-        for (int c = tid; c < PB_NCHANOUT; c += 256) a.Pkur[prow + c] = 0.f;
+        // weight 0: the row's excised power is never used for its value (detect_and_normalize3
+        // :474-476 writes 0 and leaves the bandpass alone); +inf makes the detect kernel's clip test
+        // do exactly that without having to look at the weight
+        for (int c = tid; c < PB_NCHANOUT; c += 256) a.Pkur[prow + c] = __builtin_inff();
         return;
     }
 
@@ -274,17 +278,16 @@ __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
     const uint4 *src16 = (const uint4 *)(a.in + (rbyte - o));
     const int nch = (int)((o + PB_NFFT + 15) >> 4);   // <= 783
     {
-        uint4 t[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            if (idx < nch) t[i] = src16[idx];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            if (idx < nch) ((uint4 *)buf)[idx] = t[i];
-        }
+        // nch is 782 or 783: chunks tid, tid+256, tid+512 always exist, tid+768 for tid < 15
+        const uint4 t0 = src16[tid], t1 = src16[tid + 256], t2 = src16[tid + 512];
+        const bool has3 = tid + 768 < nch;
+        uint4 t3 = make_uint4(0u, 0u, 0u, 0u);
+        if (has3) t3 = src16[tid + 768];
+        uint4 *stage = (uint4 *)buf;
+        stage[tid] = t0;
+        stage[tid + 256] = t1;
+        stage[tid + 512] = t2;
+        if (has3) stage[tid + 768] = t3;
     }
     __syncthreads();
     float2 v[25];

@@ -15,7 +15,8 @@
 //            weighted 8-row time scrunch and the 8/4/2-bit quantiser.
 // Phase B of chunk k-1 overlaps phase A of chunk k (double-buffered LDS, one barrier per
 // chunk).  The excised stream's power plane already carries pow/w (the channeliser divides
-// by the row weight, see k_channelize.hip), so no division sits on the serial path.
+// by the row weight, see k_channelize.hip; +inf for rows of weight 0), so neither a division
+// nor the row weight sits on the serial path.
 // Stream, npol and nbit are template parameters and every data-dependent choice is a select,
 // so each phase is straight-line code the scheduler can interleave across rows.
 //
@@ -102,6 +103,10 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
     const float *inA = Pant + (size_t)polA * pol_stride + cA;
     float *bpp = a.bp + (((size_t)ant * 2 + stream) * 2 + polA) * PB_NCHANOUT + cA;
     float bp = (wave == 0) ? *bpp : 0.f;
+    // row weights of the next chunk are requested one iteration ahead (rows of chunk k are the
+    // contiguous wrow[k*T .. k*T+T-1]); a load issued in the iteration that uses it would put a full
+    // memory latency on every chunk
+    float wv_next = (KUR && wave == 0 && lane < T && nchunk > 0) ? wrow[lane] : 1.f;
 
     // ---- phase B state (waves 1, 2)
     const int idxB = (wave - 1) * 64 + lane;      // group-in-chunk * 32 + channel
@@ -126,9 +131,9 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
             const int seg = k / cps, row0 = (k % cps) * T;
             const int slot = k % D2_NSLOT;
             const float *wseg = wrow + (size_t)seg * R;
-            float wv = 1.f;
+            const float wv = wv_next;
             if (KUR) {
-                wv = lane < T ? wseg[row0 + lane] : 1.f;
+                if (k + 1 < nchunk && lane < T) wv_next = wrow[(size_t)(k + 1) * T + lane];
                 if (lane < T) s_w[buf][lane] = wv;
             }
             if (row0 == 0 && bp == 0.f) {
@@ -161,10 +166,11 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
                     bp = bpn;
                     u = bp;
                 } else {
-                    const float w = readlane_f(wv, j);      // wave-uniform
+                    // rows with weight 0 arrive as +inf from the channeliser, so the 11x clip test
+                    // alone keeps the bandpass unchanged for them (:474-476) as for clipped samples
+                    // (:493-494); phase B turns their x into 0 from the row weight
                     const bool clip = pk[j] > bp * 11.f;
-                    const bool keep = (w == 0.f) | clip;     // :474-476, :493-494: bp not updated
-                    bp = keep ? bp : bpn;
+                    bp = clip ? bp : bpn;
                     u = clip ? -1.f : bp;
                 }
                 s_u[buf][j][lane] = u;

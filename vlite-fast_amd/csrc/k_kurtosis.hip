@@ -83,41 +83,32 @@ __global__ __launch_bounds__(256) void k_kurtosis_row(
     const int ant = blockIdx.y;
     const int seg = grow / R, row = grow % R;
 
-    size_t rbyte[2];
-    unsigned off[2];
-#pragma unroll
-    for (int pol = 0; pol < 2; ++pol) {
-        rbyte[pol] = (size_t)ant * in_ant_stride + ((size_t)seg * 2 + pol) * seg_samples + (size_t)row * PB_NFFT;
-        off[pol] = (unsigned)(rbyte[pol] & 15);
-    }
+    // (no runtime-indexed private arrays: they would live in scratch memory)
+    const size_t rbyte0 = (size_t)ant * in_ant_stride + ((size_t)seg * 2 + 0) * seg_samples + (size_t)row * PB_NFFT;
+    const size_t rbyte1 = rbyte0 + seg_samples;
+    const unsigned off0 = (unsigned)(rbyte0 & 15), off1 = (unsigned)(rbyte1 & 15);
     {
-        uint4 t[2][4];
-#pragma unroll
-        for (int pol = 0; pol < 2; ++pol) {
-            const uint4 *src16 = (const uint4 *)(in + (rbyte[pol] - off[pol]));
-            const int nch = (int)((off[pol] + PB_NFFT + 15) >> 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = tid + 256 * i;
-                if (idx < nch) t[pol][i] = src16[idx];
-            }
-        }
-#pragma unroll
-        for (int pol = 0; pol < 2; ++pol) {
-            const int nch = (int)((off[pol] + PB_NFFT + 15) >> 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = tid + 256 * i;
-                if (idx < nch) sraw[pol][idx] = t[pol][i];
-            }
-        }
+        // 782 or 783 aligned 16-byte chunks cover a row: tid, tid+256, tid+512 always exist
+        const uint4 *s0 = (const uint4 *)(in + (rbyte0 - off0));
+        const uint4 *s1 = (const uint4 *)(in + (rbyte1 - off1));
+        const bool h0 = tid + 768 < (int)((off0 + PB_NFFT + 15) >> 4);
+        const bool h1 = tid + 768 < (int)((off1 + PB_NFFT + 15) >> 4);
+        const uint4 a0 = s0[tid], a1 = s0[tid + 256], a2 = s0[tid + 512];
+        const uint4 b0 = s1[tid], b1 = s1[tid + 256], b2 = s1[tid + 512];
+        uint4 a3 = make_uint4(0u, 0u, 0u, 0u), b3 = a3;
+        if (h0) a3 = s0[tid + 768];
+        if (h1) b3 = s1[tid + 768];
+        sraw[0][tid] = a0; sraw[0][tid + 256] = a1; sraw[0][tid + 512] = a2;
+        sraw[1][tid] = b0; sraw[1][tid + 256] = b1; sraw[1][tid + 512] = b2;
+        if (h0) sraw[0][tid + 768] = a3;
+        if (h1) sraw[1][tid + 768] = b3;
     }
     __syncthreads();
 
     // each wave reduces blocks wave, wave+4, ...: leaves t = lane + 64 i hold (x[t]^2, x[t+250]^2)
     for (int bi = wave; bi < 50; bi += 4) {
         const int pol = bi / 25, blk = bi % 25;
-        const uint8_t *sb = (const uint8_t *)sraw[pol] + off[pol] + blk * PB_NKURTO;
+        const uint8_t *sb = (const uint8_t *)sraw[pol] + (pol ? off1 : off0) + blk * PB_NKURTO;
         float d2[4], d4[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -188,8 +179,8 @@ __global__ __launch_bounds__(256) void k_kurtosis_row(
     if (WRITE_F32) {
 #pragma unroll
         for (int pol = 0; pol < 2; ++pol) {
-            const uint32_t *sw = (const uint32_t *)((const uint8_t *)sraw[pol] + off[pol]);
-            const size_t fo = rbyte[pol];  // float index = sample index
+            const uint32_t *sw = (const uint32_t *)((const uint8_t *)sraw[pol] + (pol ? off1 : off0));
+            const size_t fo = pol ? rbyte1 : rbyte0;  // float index = sample index
             for (int i = tid; i < PB_NFFT / 4; i += 256) {
                 const float4 v = cvt4(sw[i]);
                 if (write_raw) ((float4 *)(fraw + fo))[i] = v;

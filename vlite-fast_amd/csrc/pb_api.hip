@@ -598,7 +598,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
     if (!h->cfg.inject_frb) inject_now = 0;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const bool hipfft = h->cfg.fft_backend == PB_FFT_HIPFFT;
-    // this set's previous detect + D2H must have drained before its planes are refilled
+    // this set's previous D2H must have drained before detect overwrites its code buffer
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_det, 0));
     {
         StageTimer t(h, PB_ST_KURTOSIS);
@@ -621,17 +621,16 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         HIPCHK(h, launch_channelize(h, nseg, inject_now));
         t.stop();
     }
-    // detect + the D2H of the filterbank bytes run on the second stream, so that the next
-    // batch's kurtosis/channeliser (other buffer set) overlaps them
-    HIPCHK(h, hipEventRecord(h->ev_chan, h->stream));
-    hipStream_t s_main = h->stream;
-    h->stream = h->s_det;
-    hipError_t e = hipStreamWaitEvent(h->s_det, h->ev_chan, 0);
-    if (e == hipSuccess) {
+    // All kernels stay on ONE stream: they are VALU-issue bound, so running detect beside the next
+    // batch's channeliser only stretches both (measured, profiles/r01_notes.md).  Only the D2H of the
+    // filterbank bytes goes to the second stream (copy engine), overlapping the next batch's kernels.
+    {
         StageTimer t(h, PB_ST_DETECT);
-        e = launch_detect(h, nseg, inject_now);
+        HIPCHK(h, launch_detect(h, nseg, inject_now));
         t.stop();
     }
+    HIPCHK(h, hipEventRecord(h->ev_chan, h->stream));
+    hipError_t e = hipStreamWaitEvent(h->s_det, h->ev_chan, 0);
     for (int a = 0; a < h->A && e == hipSuccess; ++a)
         for (int st = 0; st < 2 && e == hipSuccess; ++st) {
             if (st == 0 ? h->cfg.rfi_mode == 1 : h->cfg.rfi_mode == 0) continue;
@@ -640,7 +639,6 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
                                h->s_det);
         }
     if (e == hipSuccess) e = hipEventRecord(h->ev_det, h->s_det);
-    h->stream = s_main;
     HIPCHK(h, e);
     h->processed = nseg;
     h->sets[h->cur_set].processed = nseg;

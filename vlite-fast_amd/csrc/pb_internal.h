@@ -68,8 +68,8 @@ struct pb_handle {
     // --- pipeline slots: the d_* buffers above (except d_bp, d_vdif, tables) exist once per
     // set; the members above always alias the SELECTED set (pb_select_set)
     uint8_t *h_codes;      // pinned mirror of d_codes, filled asynchronously after detect
-    hipEvent_t ev_chan;    // channeliser of this set done (detect may start)
-    hipEvent_t ev_det;     // detect + D2H of this set done (set may be refilled / fetched)
+    hipEvent_t ev_chan;    // kernels of this set done (its D2H may start)
+    hipEvent_t ev_det;     // D2H of this set done (set may be refilled / fetched)
     int processed;         // segments of the last pb_process on this set
     struct BufSet {
         uint8_t *d_in, *d_flags, *d_codes, *h_codes;
@@ -80,7 +80,7 @@ struct pb_handle {
     };
     std::vector<BufSet> sets;
     int cur_set;
-    hipStream_t s_det;     // detect + D2H stream
+    hipStream_t s_det;     // D2H (copy) stream
     FftTables ft;
     DagConsts dag;
     std::map<long, hipfftHandle> plans;
