@@ -91,6 +91,27 @@ def cpu_baseline(quick=False):
 _CPU_V = None
 
 
+def measured_traffic(stage, args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (tools/profile_gpu.sh + tools/summarise_profile.py; FETCH_SIZE / WRITE_SIZE collected in separate
+    passes and corrected as MI355X_MICROARCH.md prescribes).  None when no summary matches this
+    configuration (counters cannot be collected from inside the timed run)."""
+    import glob
+    if args.backend != "lds" or args.rfi_mode != 2 or args.seg_per_step != 10 or args.ant_per_gpu != 1 or args.rfi_frac:
+        return None
+    names = {"kurtosis": "k_kurtosis_row", "channelize": "k_channelize", "detect": "k_detect2"}
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for k, t in d.get("kernels", {}).items():
+            if k.startswith(names.get(stage, "?")):
+                best = int(t["hbm_bytes_per_launch"])
+    return best
+
+
 def _cpu_chunk(arg):
     p, i, n = arg
     import oracle as O
@@ -225,6 +246,7 @@ def main():
         per_launch = alg[dom] * S * A
         achieved = per_launch / (avg_ms * 1e-3) / 1e9
         chain_bps = {2: 66.09, 1: 34.04, 0: 34.04}[args.rfi_mode]  # SURVEY.md 8(d) B per dual-pol sample
+        traffic = measured_traffic(dom, args)
         out = {
             "metric": "Msamp/s/antenna (dual-pol) and x real-time @128 MS/s; % HBM roofline",
             "value": round(msamp, 1), "unit": "Msamp/s", "n_gpus": world, "steps": args.steps,
@@ -241,7 +263,7 @@ def main():
             "x_realtime_per_antenna": round(msamp / nant_total / 128.0, 1),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                         "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_bytes_per_launch": per_launch},
             "chain_model": {"bytes_per_sample": chain_bps,
                             "equiv_GBps": round(msamp * 1e6 * chain_bps / 1e9, 1),
