@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--rfi-frac", type=float, default=0.0,
                     help="fraction of 500-sample blocks given an impulsive RFI burst (default: clean noise)")
     ap.add_argument("--nsets", type=int, default=2, help="buffer sets (1 = no batch pipelining)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -144,11 +145,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)          # (rehearsals may put several ranks on one card)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group(args.dist_backend)          # gloo: CPU rehearsal of the N > 1 path
 
     lp = importlib.import_module("vlite-fast_amd.libpb")
     S, A = args.seg_per_step, args.ant_per_gpu
@@ -181,19 +187,37 @@ def main():
                 v = h.fetch_view(a, st, S)
                 state["sink"] += int(v[0]) + int(v[-1])
 
+    ts = None
+    if world > 1:
+        # the library runs on a torch stream so that kernels -> RCCL reduce -> requantise are ordered on
+        # the device, with no host synchronisation inside a step
+        ts = torch.cuda.Stream(device=dev)
+        h.sync()
+        h.set_stream(ts.cuda_stream)
+
     def step():
         k = state["k"]
         h.select_set(k % NSETS)
-        h.process(S)
-        if world > 1:
-            h.coadd_local(S, d_sum.data_ptr())
-            h.sync()                      # library streams -> visible to the RCCL stream
-            dist.reduce(d_sum, dst=0, op=dist.ReduceOp.SUM)
-            torch.cuda.synchronize()
-            if rank == 0:
-                h.coadd_finish(S, d_sum.data_ptr(), nant_total)
+        if world == 1:
+            h.process(S)
+        else:
+            with torch.cuda.stream(ts):
+                h.process(S)
+                h.coadd_local(S, d_sum.data_ptr())
+                if args.dist_backend == "nccl":
+                    dist.reduce(d_sum, dst=0, op=dist.ReduceOp.SUM)
+                else:                     # gloo rehearsal: through host memory
+                    ts.synchronize()
+                    t = d_sum.cpu()
+                    dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+                    d_sum.copy_(t)
+                if rank == 0:
+                    h.coadd_finish(S, d_sum.data_ptr(), nant_total, blocking=False)
         if k >= NSETS - 1:
             collect(k - (NSETS - 1))
+            if world > 1 and rank == 0:
+                v = h.coadd_view(S, age=1)            # coadded bytes of the previous batch
+                state["sink"] += int(v[0])
         state["k"] = k + 1
 
     def drain():
@@ -222,7 +246,7 @@ def main():
     h.profile(False)
     tm = h.timers(reset=True)
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

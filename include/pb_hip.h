@@ -170,7 +170,9 @@ int pb_output_dev(pb_handle *h, int ant, int stream, void **codes, void **ave);
  * codes = sel_and_dig(d_sum / sqrt(nant_total)). */
 int pb_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate);
 int pb_coadd_finish(pb_handle *h, int nseg, const float *d_sum, int nant_total,
-                    uint8_t *codes_host);
+                    uint8_t *codes_host);   /* codes_host NULL: asynchronous, see pb_coadd_fetch_ptr */
+/* pinned-host view of the coadded bytes of the latest (age 0) or previous (age 1) pb_coadd_finish */
+int pb_coadd_fetch_ptr(pb_handle *h, int age, const uint8_t **codes);
 
 int pb_profile(pb_handle *h, int enable);
 int pb_get_timers(pb_handle *h, pb_timers *out, int reset);

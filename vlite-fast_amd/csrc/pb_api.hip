@@ -299,6 +299,9 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
     h->processed = 0;
     h->cur_set = 0;
     h->s_det = nullptr;
+    h->d_coadd_codes = h->h_coadd_codes = nullptr;
+    h->ev_coadd[0] = h->ev_coadd[1] = nullptr;
+    h->coadd_slot = h->coadd_last = 0;
     memset(&h->ft, 0, sizeof h->ft);
     h->profile = false;
     h->ev0 = h->ev1 = nullptr;
@@ -342,6 +345,10 @@ extern "C" void pb_destroy(pb_handle *h)
                     h->ft.tw3, h->ft.post, h->ft.postc, h->ft.taps};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->d_coadd_codes) (void)hipFree(h->d_coadd_codes);
+    if (h->h_coadd_codes) (void)hipHostFree(h->h_coadd_codes);
+    for (int i = 0; i < 2; ++i)
+        if (h->ev_coadd[i]) (void)hipEventDestroy(h->ev_coadd[i]);
     if (h->s_det) (void)hipStreamDestroy(h->s_det);
     drain_timers(h);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -725,26 +732,57 @@ extern "C" int pb_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumula
     if (!h->cfg.keep_ave) return fail(h, PB_ESTATE, "pb_coadd_local needs keep_ave=1");
     if (nseg < 1 || nseg > h->S) return fail(h, PB_EINVAL, "pb_coadd_local: nseg out of range");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_det, 0));   // the fp32 planes come from detect
+    // (the fp32 planes come from detect, which runs on this same stream)
     StageTimer t(h, PB_ST_COADD);
     HIPCHK(h, launch_coadd_local(h, nseg, d_sum, accumulate));
     t.stop();
     return PB_OK;
 }
 
+// Root side of the incoherent sum: scale by 1/sqrt(N), requantise on the GPU, bring the bytes to
+// pinned host memory asynchronously.  codes_host != NULL: wait and copy out (simple, blocking).
+// codes_host == NULL: return at once; the bytes of call k are read with pb_coadd_fetch_ptr after
+// later work has been queued (two pinned buffers alternate), so the root does not stall per batch.
 extern "C" int pb_coadd_finish(pb_handle *h, int nseg, const float *d_sum, int nant_total, uint8_t *codes_host)
 {
-    if (!h || !d_sum || !codes_host || nant_total < 1) return PB_EINVAL;
+    if (!h || !d_sum || nant_total < 1) return PB_EINVAL;
     if (nseg < 1 || nseg > h->S) return fail(h, PB_EINVAL, "pb_coadd_finish: nseg out of range");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    uint8_t *d_codes = nullptr;
-    HIPCHK(h, hipMalloc((void **)&d_codes, (size_t)nseg * h->trim));
+    const size_t nb = (size_t)h->S * h->trim;
+    if (!h->d_coadd_codes) {
+        HIPCHK(h, dmalloc(h, &h->d_coadd_codes, 2 * nb));
+        HIPCHK(h, hipHostMalloc((void **)&h->h_coadd_codes, 2 * nb, hipHostMallocDefault));
+        for (int i = 0; i < 2; ++i) HIPCHK(h, hipEventCreateWithFlags(&h->ev_coadd[i], hipEventDisableTiming));
+        h->coadd_slot = 0;
+    }
+    const int slot = h->coadd_slot;
+    h->coadd_slot ^= 1;
+    h->coadd_last = slot;
     const float scale = (float)(1.0 / sqrt((double)nant_total));
-    hipError_t e = launch_coadd_digitise(h, nseg, d_sum, scale, d_codes);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e == hipSuccess) e = hipMemcpy(codes_host, d_codes, (size_t)nseg * h->trim, hipMemcpyDeviceToHost);
-    (void)hipFree(d_codes);
-    HIPCHK(h, e);
+    // the slot's previous D2H (two calls ago) must be done before its device buffer is rewritten
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_coadd[slot], 0));
+    HIPCHK(h, launch_coadd_digitise(h, nseg, d_sum, scale, h->d_coadd_codes + slot * nb));
+    HIPCHK(h, hipEventRecord(h->ev_chan, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->s_det, h->ev_chan, 0));
+    HIPCHK(h, hipMemcpyAsync(h->h_coadd_codes + slot * nb, h->d_coadd_codes + slot * nb, (size_t)nseg * h->trim,
+                             hipMemcpyDeviceToHost, h->s_det));
+    HIPCHK(h, hipEventRecord(h->ev_coadd[slot], h->s_det));
+    if (codes_host) {
+        HIPCHK(h, hipEventSynchronize(h->ev_coadd[slot]));
+        memcpy(codes_host, h->h_coadd_codes + slot * nb, (size_t)nseg * h->trim);
+    }
+    return PB_OK;
+}
+
+extern "C" int pb_coadd_fetch_ptr(pb_handle *h, int age, const uint8_t **codes)
+{
+    if (!h || !codes) return PB_EINVAL;
+    if (!h->d_coadd_codes) return fail(h, PB_ESTATE, "pb_coadd_fetch_ptr: no pb_coadd_finish yet");
+    if (age < 0 || age > 1) return fail(h, PB_EINVAL, "pb_coadd_fetch_ptr: age must be 0 (latest) or 1 (previous)");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int slot = age == 0 ? h->coadd_last : (h->coadd_last ^ 1);
+    HIPCHK(h, hipEventSynchronize(h->ev_coadd[slot]));
+    *codes = h->h_coadd_codes + (size_t)slot * h->S * h->trim;
     return PB_OK;
 }
 

@@ -81,6 +81,9 @@ struct pb_handle {
     std::vector<BufSet> sets;
     int cur_set;
     hipStream_t s_det;     // D2H (copy) stream
+    uint8_t *d_coadd_codes, *h_coadd_codes;   // [2][S*trim] coadded bytes (device / pinned), lazily
+    hipEvent_t ev_coadd[2];
+    int coadd_slot, coadd_last;
     FftTables ft;
     DagConsts dag;
     std::map<long, hipfftHandle> plans;

@@ -52,7 +52,7 @@ class PbTimers(C.Structure):
 EXPORTS = ["pb_config_default", "pb_create", "pb_destroy", "pb_last_error", "pb_query",
            "pb_set_stream", "pb_sync", "pb_reset_bandpass", "pb_get_bandpass", "pb_set_bandpass",
            "pb_submit_planar", "pb_submit_planar_dev", "pb_submit_vdif", "pb_input_dev", "pb_process", "pb_set_frb_params", "pb_select_set", "pb_fetch", "pb_fetch_ptr",
-           "pb_output_dev", "pb_coadd_local", "pb_coadd_finish", "pb_profile", "pb_get_timers",
+           "pb_output_dev", "pb_coadd_local", "pb_coadd_finish", "pb_coadd_fetch_ptr", "pb_profile", "pb_get_timers",
            "pb_debug_fetch", "pb_channelize_f32", "pb_version"]
 
 _lib = None
@@ -102,6 +102,7 @@ def load():
     L.pb_output_dev.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp)]
     L.pb_coadd_local.argtypes = [vp, C.c_int, vp, C.c_int]
     L.pb_coadd_finish.argtypes = [vp, C.c_int, vp, C.c_int, u8p]
+    L.pb_coadd_fetch_ptr.argtypes = [vp, C.c_int, C.POINTER(u8p)]
     L.pb_profile.argtypes = [vp, C.c_int]
     L.pb_get_timers.argtypes = [vp, C.POINTER(PbTimers), C.c_int]
     L.pb_debug_fetch.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
@@ -260,10 +261,19 @@ class PbHandle(object):
     def coadd_local(self, nseg, d_sum_ptr, accumulate=False):
         self._chk(self._L.pb_coadd_local(self._h, nseg, C.c_void_p(d_sum_ptr), int(accumulate)))
 
-    def coadd_finish(self, nseg, d_sum_ptr, nant_total):
+    def coadd_finish(self, nseg, d_sum_ptr, nant_total, blocking=True):
+        if not blocking:
+            self._chk(self._L.pb_coadd_finish(self._h, nseg, C.c_void_p(d_sum_ptr), nant_total, None))
+            return None
         codes = np.empty(nseg * self.trim, np.uint8)
         self._chk(self._L.pb_coadd_finish(self._h, nseg, C.c_void_p(d_sum_ptr), nant_total, _u8(codes)))
         return codes
+
+    def coadd_view(self, nseg, age=0):
+        """Zero-copy view of the coadded bytes of the latest (age 0) / previous (age 1) finish."""
+        p = C.POINTER(C.c_uint8)()
+        self._chk(self._L.pb_coadd_fetch_ptr(self._h, age, C.byref(p)))
+        return np.ctypeslib.as_array(p, shape=(nseg * self.trim,))
 
     def profile(self, enable=True):
         self._chk(self._L.pb_profile(self._h, int(enable)))
