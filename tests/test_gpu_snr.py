@@ -73,10 +73,12 @@ def test_config3_dm500_pulse_8_antennas(oracle):
         for sec in range(NSEC):
             for a in range(A):
                 g.manual_seed(1000 * (42 + a) + sec)        # independent noise per antenna (seed 42+ant)
+                xs = [(torch.randn(2 * n, device=dev, generator=g) * 16.9 + 128.5).clamp_(0, 255).to(torch.uint8)
+                      for s in range(S)]
+                torch.cuda.synchronize()          # torch's stream and the library's are different streams
                 for s in range(S):
-                    x = (torch.randn(2 * n, device=dev, generator=g) * 16.9 + 128.5).clamp_(0, 255).to(torch.uint8)
-                    h.submit_planar_dev(a, s, x.data_ptr(), x.data_ptr() + n, n)
-                h.sync()
+                    h.submit_planar_dev(a, s, xs[s].data_ptr(), xs[s].data_ptr() + n, n)
+                h.sync()                          # copies done before torch may recycle xs
             inject_now = 0 if sec < 1 else 1 + S * (sec - 1)      # the pulse enters the band at t = 1 s
             h.process(S, inject_now)
             for a in range(A):

@@ -14,6 +14,7 @@ static hipError_t sync_all(pb_handle *h)
 {
     hipError_t e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess && h->s_det) e = hipStreamSynchronize(h->s_det);
+    if (e == hipSuccess && h->s_kur) e = hipStreamSynchronize(h->s_kur);
     return e;
 }
 
@@ -195,6 +196,10 @@ static int create_impl(pb_handle *h)
         HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(h, hipStreamCreateWithPriority(&h->s_det, hipStreamNonBlocking, hi));
     }
+    HIPCHK(h, hipStreamCreateWithFlags(&h->s_kur, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fftdone, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_kur, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_alldone, hipEventDisableTiming));
     const size_t A = h->A, S = h->S, R = h->R;
     const size_t in_elems = A * S * 2 * h->seg_samples;
     HIPCHK(h, dmalloc(h, &h->d_bp, A * 2 * 2 * PB_NCHANOUT));
@@ -299,6 +304,9 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
     h->processed = 0;
     h->cur_set = 0;
     h->s_det = nullptr;
+    h->s_kur = nullptr;
+    h->ev_fftdone = h->ev_kur = h->ev_alldone = nullptr;
+    h->last_set = -1;
     h->d_coadd_codes = h->h_coadd_codes = nullptr;
     h->ev_coadd[0] = h->ev_coadd[1] = nullptr;
     h->coadd_slot = h->coadd_last = 0;
@@ -350,6 +358,10 @@ extern "C" void pb_destroy(pb_handle *h)
     for (int i = 0; i < 2; ++i)
         if (h->ev_coadd[i]) (void)hipEventDestroy(h->ev_coadd[i]);
     if (h->s_det) (void)hipStreamDestroy(h->s_det);
+    if (h->s_kur) { (void)hipStreamSynchronize(h->s_kur); (void)hipStreamDestroy(h->s_kur); }
+    if (h->ev_fftdone) (void)hipEventDestroy(h->ev_fftdone);
+    if (h->ev_kur) (void)hipEventDestroy(h->ev_kur);
+    if (h->ev_alldone) (void)hipEventDestroy(h->ev_alldone);
     drain_timers(h);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -400,6 +412,18 @@ extern "C" int pb_sync(pb_handle *h)
     return PB_OK;
 }
 
+// Stream that input staging goes to.  With >= 2 buffer sets the next batch is staged while the
+// previous one computes: staging and the kurtosis pass share s_kur (ordered), the channeliser on the
+// main stream waits for the kurtosis event.  Refilling the set that was processed last waits for
+// that whole batch.
+static hipError_t submit_stream(pb_handle *h, hipStream_t *out)
+{
+    if (h->sets.size() < 2) { *out = h->stream; return hipSuccess; }
+    *out = h->s_kur;
+    if (h->last_set == h->cur_set) return hipStreamWaitEvent(h->s_kur, h->ev_alldone, 0);
+    return hipSuccess;
+}
+
 static int check_ant(pb_handle *h, int ant)
 {
     if (ant < 0 || ant >= h->A) return fail(h, PB_EINVAL, "antenna index out of range");
@@ -447,8 +471,10 @@ extern "C" int pb_submit_planar(pb_handle *h, int ant, int seg, const uint8_t *p
     if (nsamp != h->seg_samples) return fail(h, PB_EINVAL, "pb_submit_planar: nsamp must equal seg_samples_per_pol");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     uint8_t *dst = h->d_in + (((size_t)ant * h->S + seg) * 2) * h->seg_samples;
-    HIPCHK(h, hipMemcpyAsync(dst, pol0, nsamp, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(dst + h->seg_samples, pol1, nsamp, hipMemcpyHostToDevice, h->stream));
+    hipStream_t ss;
+    HIPCHK(h, submit_stream(h, &ss));
+    HIPCHK(h, hipMemcpyAsync(dst, pol0, nsamp, hipMemcpyHostToDevice, ss));
+    HIPCHK(h, hipMemcpyAsync(dst + h->seg_samples, pol1, nsamp, hipMemcpyHostToDevice, ss));
     return PB_OK;
 }
 
@@ -460,8 +486,10 @@ extern "C" int pb_submit_planar_dev(pb_handle *h, int ant, int seg, const void *
     if (nsamp != h->seg_samples) return fail(h, PB_EINVAL, "pb_submit_planar_dev: nsamp must equal seg_samples_per_pol");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     uint8_t *dst = h->d_in + (((size_t)ant * h->S + seg) * 2) * h->seg_samples;
-    HIPCHK(h, hipMemcpyAsync(dst, pol0, nsamp, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(dst + h->seg_samples, pol1, nsamp, hipMemcpyDeviceToDevice, h->stream));
+    hipStream_t ss;
+    HIPCHK(h, submit_stream(h, &ss));
+    HIPCHK(h, hipMemcpyAsync(dst, pol0, nsamp, hipMemcpyDeviceToDevice, ss));
+    HIPCHK(h, hipMemcpyAsync(dst + h->seg_samples, pol1, nsamp, hipMemcpyDeviceToDevice, ss));
     return PB_OK;
 }
 
@@ -502,10 +530,18 @@ extern "C" int pb_submit_vdif(pb_handle *h, int ant, int seg0, const uint8_t *bl
         HIPCHK(h, hipMalloc((void **)&h->d_frame_idx, 2 * nfr * sizeof(int32_t)));
         h->vdif_cap = nbytes;
     }
-    HIPCHK(h, hipMemcpyAsync(h->d_vdif, block, nbytes, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_frame_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));  // idx is a local
-    HIPCHK(h, launch_deframe(h, ant, seg0, nfr));
+    hipStream_t ss;
+    HIPCHK(h, submit_stream(h, &ss));
+    HIPCHK(h, hipMemcpyAsync(h->d_vdif, block, nbytes, hipMemcpyHostToDevice, ss));
+    HIPCHK(h, hipMemcpyAsync(h->d_frame_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, ss));
+    HIPCHK(h, hipStreamSynchronize(ss));  // idx is a local
+    {
+        hipStream_t s_main = h->stream;
+        h->stream = ss;
+        hipError_t e = launch_deframe(h, ant, seg0, nfr);
+        h->stream = s_main;
+        HIPCHK(h, e);
+    }
     return PB_OK;
 }
 
@@ -608,10 +644,33 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
     // this set's previous D2H must have drained before detect overwrites its code buffer
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_det, 0));
     {
-        StageTimer t(h, PB_ST_KURTOSIS);
-        HIPCHK(h, launch_kurtosis_flag(h, nseg, hipfft));
-        if (h->cfg.rfi_mode) HIPCHK(h, launch_row_weights(h, nseg));
-        t.stop();
+        // The kurtosis pass only needs the raw bytes, and it is a light memory/LDS kernel while
+        // detect of the PREVIOUS batch is a latency-bound one that leaves the CUs mostly idle: when
+        // the previous batch used another buffer set, run kurtosis on its own stream, released as
+        // soon as the previous channeliser has finished, i.e. beside the previous detect.
+        const bool overlap = !hipfft && h->sets.size() >= 2 && h->last_set >= 0 && h->last_set != h->cur_set;
+        hipStream_t s_main = h->stream;
+        hipError_t e = hipSuccess;
+        if (overlap) {
+            e = hipStreamWaitEvent(h->s_kur, h->ev_fftdone, 0);
+            h->stream = h->s_kur;
+        } else if (h->sets.size() >= 2) {
+            // staging went to s_kur: the main stream must see it
+            e = hipEventRecord(h->ev_kur, h->s_kur);
+            if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->ev_kur, 0);
+        }
+        if (e == hipSuccess) {
+            StageTimer t(h, PB_ST_KURTOSIS);
+            e = launch_kurtosis_flag(h, nseg, hipfft);
+            if (e == hipSuccess && h->cfg.rfi_mode) e = launch_row_weights(h, nseg);
+            t.stop();
+        }
+        if (overlap) {
+            if (e == hipSuccess) e = hipEventRecord(h->ev_kur, h->s_kur);
+            h->stream = s_main;
+            if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->ev_kur, 0);
+        }
+        HIPCHK(h, e);
     }
     if (hipfft) {
         StageTimer t(h, PB_ST_FFT);
@@ -628,6 +687,8 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         HIPCHK(h, launch_channelize(h, nseg, inject_now));
         t.stop();
     }
+    HIPCHK(h, hipEventRecord(h->ev_fftdone, h->stream));
+    h->last_set = h->cur_set;
     // All kernels stay on ONE stream: they are VALU-issue bound, so running detect beside the next
     // batch's channeliser only stretches both (measured, profiles/r01_notes.md).  Only the D2H of the
     // filterbank bytes goes to the second stream (copy engine), overlapping the next batch's kernels.
@@ -637,6 +698,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         t.stop();
     }
     HIPCHK(h, hipEventRecord(h->ev_chan, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev_alldone, h->stream));
     hipError_t e = hipStreamWaitEvent(h->s_det, h->ev_chan, 0);
     for (int a = 0; a < h->A && e == hipSuccess; ++a)
         for (int st = 0; st < 2 && e == hipSuccess; ++st) {

@@ -81,6 +81,9 @@ struct pb_handle {
     std::vector<BufSet> sets;
     int cur_set;
     hipStream_t s_det;     // D2H (copy) stream
+    hipStream_t s_kur;     // kurtosis of the next batch, beside detect of the previous one
+    hipEvent_t ev_fftdone, ev_kur, ev_alldone;
+    int last_set;          // buffer set of the previous pb_process (-1: none)
     uint8_t *d_coadd_codes, *h_coadd_codes;   // [2][S*trim] coadded bytes (device / pinned), lazily
     hipEvent_t ev_coadd[2];
     int coadd_slot, coadd_last;
