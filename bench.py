@@ -97,7 +97,8 @@ def measured_traffic(stage, args):
     passes and corrected as MI355X_MICROARCH.md prescribes).  None when no summary matches this
     configuration (counters cannot be collected from inside the timed run)."""
     import glob
-    if args.backend != "lds" or args.rfi_mode != 2 or args.seg_per_step != 10 or args.ant_per_gpu != 1 or args.rfi_frac:
+    if (args.backend != "lds" or args.rfi_mode != 2 or args.seg_per_step != 10 or args.ant_per_gpu != 1
+            or args.rfi_frac or args.taps != 1):
         return None
     names = {"kurtosis": "k_kurtosis_row", "channelize": "k_channelize", "detect": "k_detect2"}
     best = None
@@ -133,6 +134,7 @@ def main():
     ap.add_argument("--ant-per-gpu", type=int, default=1)
     ap.add_argument("--rfi-frac", type=float, default=0.0,
                     help="fraction of 500-sample blocks given an impulsive RFI burst (default: clean noise)")
+    ap.add_argument("--taps", type=int, default=1, help="1 = rectangular window (reference GPU path), 4 = PFB")
     ap.add_argument("--nsets", type=int, default=2, help="buffer sets (1 = no batch pipelining)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -162,7 +164,8 @@ def main():
     NSETS = args.nsets   # 2 = double-buffered batches: the D2H of second k and the host's collection of it overlap
                 # the kernels of second k+1
     h = lp.PbHandle(device=local, nant=A, nbit=args.nbit, npol=1, rfi_mode=args.rfi_mode,
-                    fft_backend=backend, rows_per_seg=ROWS, max_seg=S, keep_ave=(world > 1), nsets=NSETS)
+                    fft_backend=backend, rows_per_seg=ROWS, max_seg=S, keep_ave=(world > 1), nsets=NSETS,
+                    taps=args.taps)
     n = h.seg_samples
     for a in range(A):
         sec = synth_second(torch, dev, 42 + rank * A + a, n, S, rfi_frac=args.rfi_frac)
@@ -280,7 +283,7 @@ def main():
                     "%g%% of 500-sample blocks with impulsive RFI; resident in HBM" % (100 * args.rfi_frac),
             "config": {"workload": "configs[1]: 1 antenna/GPU, 128 MS/s dual-pol, 1 s per step "
                                    "(10 x 100-ms segments, 2048 x 12500-pt FFT rows each), RFI mode %d, "
-                                   "%d-bit out, taps=1, %s FFT" % (args.rfi_mode, args.nbit, args.backend),
+                                   "%d-bit out, taps=%d, %s FFT" % (args.rfi_mode, args.nbit, args.taps, args.backend),
                        "antennas": nant_total, "antennas_per_gpu": A, "segments_per_step": S,
                        "parallelism": "antenna-per-GPU" + ("+rccl-reduce-coadd" if world > 1 else "")},
             "msamp_per_antenna": round(msamp / nant_total, 1),

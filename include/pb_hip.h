@@ -117,6 +117,9 @@ int pb_sync(pb_handle *h);
 /* bandpass state bp_dev / bp_kur_dev (:700-709): zero = "initialise from the next
  * segment's mean" (src/pb_kernels.cu:406-411,444-461).  Compact [2 pols][4096]. */
 int pb_reset_bandpass(pb_handle *h, int ant);
+/* taps=4 only: forget the three rows the FIR window carries over from the previous call (start of
+ * a new observation).  No-op for taps=1. */
+int pb_reset_history(pb_handle *h, int ant);
 int pb_get_bandpass(pb_handle *h, int ant, float *bp_raw, float *bp_kur);
 int pb_set_bandpass(pb_handle *h, int ant, const float *bp_raw, const float *bp_kur);
 

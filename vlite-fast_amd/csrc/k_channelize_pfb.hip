@@ -1,0 +1,259 @@
+// taps = 4: the 4-tap Hamming WOLA polyphase window of the reference's NumPy channeliser
+// (analysis/baseband.py:1207-1237) in the streaming 8-bit path.
+//
+// The reference's GPU path has no PFB (rectangular window only); this mode is the north_star's
+// "4-tap polyphase FIR window" and is defined here as the causal form of polyphase_filterbank:
+//     output row g  =  rfft( sum_{j=0..3} taps[j] (.) v_{g-3+j} ),   v = unpacked voltages,
+// i.e. output row g is the reference function's spectrum i = g - 3 of the same sample stream; rows
+// before the start of the stream are zeros.  The three most recent rows (and their kurtosis flags)
+// are kept per antenna between pb_process calls.  Excision zeroes flagged 500-sample blocks of each
+// contributing row before the window is applied; the row weight generalises apply_kurtosis'
+// "fraction of unflagged samples" to the window's energy:
+//     w(g) = sum_{j,b unflagged and present} E[j][b] / sum_{j,b} E[j][b],  E[j][b] = sum_{m in b} taps[j][m]^2.
+// Parity: spectra vs polyphase_filterbank golden (tests, 2e-6), whole chain vs the oracle's kernels
+// composed around the same fp32 FIR (bit-exact, RFI mode 0); the weight definition has no reference.
+#include "fft_lds.h"
+
+#define PFB_ROW_LDS 12528    // 12500 bytes + up to 12 of alignment slack, padded to 16
+#define PFB_HIST_STRIDE 12512
+
+struct PfbArgs {
+    const uint8_t *in;       // [A][S][2][seg_samples]
+    size_t in_ant_stride, seg_samples;
+    const uint8_t *hist;     // [A][2][3][PFB_HIST_STRIDE]
+    const uint8_t *flags;    // [A][S*R*25]
+    size_t flags_ant_stride;
+    const uint8_t *hflags;   // [A][3][25]
+    const uint8_t *hvalid;   // [A][3] history slot holds data
+    const float *wrow;       // [A][S*R]  (already the PFB weights)
+    size_t wrow_ant_stride;
+    const float *fir;        // [4][12500]
+    float *Praw, *Pkur;
+    size_t p_ant_stride;
+    const float2 *tw2, *tw3, *postc;
+    FrbParams frb;
+    int R, rfi_mode, inject_now;
+};
+
+__device__ __forceinline__ unsigned row_mask(const PfbArgs &a, int ant, int rr)
+{
+    // flags of the 25 blocks of row rr (rr < 0: history slot 3 + rr); uniform -> scalar loads
+    const uint8_t *f = rr >= 0 ? a.flags + (size_t)ant * a.flags_ant_stride + (size_t)rr * PB_BLK_PER_FFT
+                               : a.hflags + ((size_t)ant * 3 + (3 + rr)) * PB_BLK_PER_FFT;
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < PB_BLK_PER_FFT; ++r) m |= (f[r] ? 1u : 0u) << r;
+    return __builtin_amdgcn_readfirstlane(m);
+}
+
+__global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * PFB_ROW_LDS];   // 50 112 B, reused as the FFT buffer
+    float2 *buf = (float2 *)lds;
+    const int tid = threadIdx.x;
+    const int grow = blockIdx.x;
+    const int pol = blockIdx.y & 1, ant = blockIdx.z;
+    const int role = a.rfi_mode == 2 ? (blockIdx.y >> 1) : (a.rfi_mode == 1 ? 1 : 0);
+    const int seg = grow / a.R, row = grow % a.R;
+
+    // zeroing masks of the four contributing rows.  A history slot that holds no data yet (start of
+    // the stream) is all zeros: nothing to excise there (its missing weight is booked by k_pfb_weights).
+    unsigned mask[4] = {0, 0, 0, 0};
+    unsigned differ = 0;
+    if (a.rfi_mode) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rr = grow - 3 + j;
+            const bool present = rr >= 0 || a.hvalid[ant * 3 + (3 + rr)] != 0;
+            mask[j] = present ? row_mask(a, ant, rr) : 0u;
+            differ |= mask[j];
+        }
+    }
+    differ = __builtin_amdgcn_readfirstlane(differ);
+    if (a.rfi_mode == 2 && role == 1 && differ == 0) return;
+
+    const float w = a.rfi_mode ? a.wrow[(size_t)ant * a.wrow_ant_stride + grow] : 1.f;
+    const size_t prow = (size_t)ant * a.p_ant_stride + (((size_t)seg * 2 + pol) * a.R + row) * PB_NCHANOUT;
+    if (role == 1 && w == 0.f) {
+        for (int c = tid; c < PB_NCHANOUT; c += 256) a.Pkur[prow + c] = __builtin_inff();
+        return;
+    }
+
+    // stage the four rows (16-byte loads of the aligned chunks that cover each row)
+    unsigned off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rr = grow - 3 + j;
+        const uint8_t *base;
+        size_t rbyte;
+        if (rr >= 0) {
+            rbyte = (size_t)ant * a.in_ant_stride + ((size_t)(rr / a.R) * 2 + pol) * a.seg_samples +
+                    (size_t)(rr % a.R) * PB_NFFT;
+            base = a.in;
+        } else {
+            rbyte = (((size_t)ant * 2 + pol) * 3 + (3 + rr)) * PFB_HIST_STRIDE;
+            base = a.hist;
+        }
+        const unsigned o = (unsigned)(rbyte & 15);
+        off[j] = o;
+        const uint4 *src16 = (const uint4 *)(base + (rbyte - o));
+        const int nch = (int)((o + PB_NFFT + 15) >> 4);
+        uint4 *dst = (uint4 *)(lds + j * PFB_ROW_LDS);
+        for (int i = tid; i < nch; i += 256) dst[i] = src16[i];
+    }
+    __syncthreads();
+
+    float2 v[25];
+    if (tid < 250) {
+        const bool kur = role == 1;
+        const uint16_t *s0 = (const uint16_t *)(lds + 0 * PFB_ROW_LDS + off[0]);
+        const uint16_t *s1 = (const uint16_t *)(lds + 1 * PFB_ROW_LDS + off[1]);
+        const uint16_t *s2 = (const uint16_t *)(lds + 2 * PFB_ROW_LDS + off[2]);
+        const uint16_t *s3 = (const uint16_t *)(lds + 3 * PFB_ROW_LDS + off[3]);
+#pragma unroll
+        for (int r = 0; r < 25; ++r) {
+            const int n = tid + 250 * r;
+            const unsigned w0 = (kur && ((mask[0] >> r) & 1u)) ? 0u : s0[n];
+            const unsigned w1 = (kur && ((mask[1] >> r) & 1u)) ? 0u : s1[n];
+            const unsigned w2 = (kur && ((mask[2] >> r) & 1u)) ? 0u : s2[n];
+            const unsigned w3 = (kur && ((mask[3] >> r) & 1u)) ? 0u : s3[n];
+            const float2 t0 = *(const float2 *)(a.fir + 0 * PB_NFFT + 2 * n);
+            const float2 t1 = *(const float2 *)(a.fir + 1 * PB_NFFT + 2 * n);
+            const float2 t2 = *(const float2 *)(a.fir + 2 * PB_NFFT + 2 * n);
+            const float2 t3 = *(const float2 *)(a.fir + 3 * PB_NFFT + 2 * n);
+            // sum_j taps[j] * x_j, products then left-to-right adds (the order of k_channelize_f32)
+            float ax = t0.x * cvt_sample_c(w0 & 0xff);
+            float ay = t0.y * cvt_sample_c(w0 >> 8);
+            const float p1x = t1.x * cvt_sample_c(w1 & 0xff), p1y = t1.y * cvt_sample_c(w1 >> 8);
+            ax = ax + p1x;
+            ay = ay + p1y;
+            const float p2x = t2.x * cvt_sample_c(w2 & 0xff), p2y = t2.y * cvt_sample_c(w2 >> 8);
+            ax = ax + p2x;
+            ay = ay + p2y;
+            const float p3x = t3.x * cvt_sample_c(w3 & 0xff), p3y = t3.y * cvt_sample_c(w3 >> 8);
+            ax = ax + p3x;
+            ay = ay + p3y;
+            v[r] = make_float2(ax, ay);
+        }
+    }
+    __syncthreads();
+    fft6250(v, buf, a.tw2, a.tw3, tid);
+
+    const bool inject = a.frb.delays != nullptr && a.inject_now > 0;
+    const int since = inject ? (a.inject_now - 1 + seg) * a.R : 0;
+    const bool also_kur = a.rfi_mode == 2 && role == 0 && differ == 0;
+    float *P0 = (role == 1 ? a.Pkur : a.Praw) + prow;
+    float *P1 = a.Pkur + prow;
+    for (int c4 = tid * 4; c4 < PB_NCHANOUT; c4 += 1024) {
+        const float4 t01 = *(const float4 *)(a.postc + c4);
+        const float4 t23 = *(const float4 *)(a.postc + c4 + 2);
+        const float2 tw[4] = {make_float2(t01.x, t01.y), make_float2(t01.z, t01.w), make_float2(t23.x, t23.y),
+                              make_float2(t23.z, t23.w)};
+        float pw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = PB_CHANMIN + c4 + q;
+            const float2 za = buf[k == M_HALF ? 0 : k];
+            float2 zb = buf[M_HALF - k];
+            zb.y = -zb.y;
+            const float2 E = make_float2(za.x + zb.x, za.y + zb.y);
+            const float2 O = make_float2(za.x - zb.x, za.y - zb.y);
+            const float2 Pq = cmul(O, tw[q]);
+            float2 X = make_float2(0.5f * (E.x + Pq.x), 0.5f * (E.y + Pq.y));
+            if (inject) {
+                const float d = a.frb.delays[k];
+                const int lo = (int)(d + 0.5) - since;
+                const int hi = (int)(d + a.frb.width + 0.5) - since;
+                if (row >= lo && row <= hi) {
+                    X.x *= a.frb.amp;
+                    X.y *= a.frb.amp;
+                }
+            }
+            const float xx = X.x * X.x;
+            const float yy = X.y * X.y;
+            pw[q] = xx + yy;
+        }
+        if (role == 0) *(float4 *)(P0 + c4) = make_float4(pw[0], pw[1], pw[2], pw[3]);
+        if (role == 1 || also_kur)
+            *(float4 *)((role == 1 ? P0 : P1) + c4) = make_float4(pw[0] / w, pw[1] / w, pw[2] / w, pw[3] / w);
+    }
+}
+
+// row weights of the PFB mode (see the header comment); overwrites wrow[g]
+__global__ void k_pfb_weights(const uint8_t *__restrict__ flags, size_t flags_ant_stride,
+                              const uint8_t *__restrict__ hflags, const float *__restrict__ tapE,
+                              float *__restrict__ wrow, size_t wrow_ant_stride, int nrows)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ant = blockIdx.y;
+    if (g >= nrows) return;
+    float s = 0.f;
+    for (int j = 0; j < 4; ++j) {
+        const int rr = g - 3 + j;
+        const uint8_t *f = rr >= 0 ? flags + (size_t)ant * flags_ant_stride + (size_t)rr * PB_BLK_PER_FFT
+                                   : hflags + ((size_t)ant * 3 + (3 + rr)) * PB_BLK_PER_FFT;
+        for (int b = 0; b < PB_BLK_PER_FFT; ++b)
+            if (!f[b]) s = s + tapE[j * PB_BLK_PER_FFT + b];
+    }
+    wrow[(size_t)ant * wrow_ant_stride + g] = s / tapE[100];
+}
+
+// keep the last three rows (and flags) of the batch for the next call
+__global__ void k_pfb_history(const uint8_t *__restrict__ in, size_t in_ant_stride, size_t seg_samples,
+                              const uint8_t *__restrict__ flags, size_t flags_ant_stride,
+                              uint8_t *__restrict__ hist, uint8_t *__restrict__ hflags,
+                              uint8_t *__restrict__ hvalid, int R, int nrows)
+{
+    const int j = blockIdx.x;          // history slot 0..2 <- row nrows-3+j
+    const int pol = blockIdx.y, ant = blockIdx.z;
+    const int rr = nrows - 3 + j;
+    const uint8_t *src = in + (size_t)ant * in_ant_stride + ((size_t)(rr / R) * 2 + pol) * seg_samples +
+                         (size_t)(rr % R) * PB_NFFT;
+    uint8_t *dst = hist + (((size_t)ant * 2 + pol) * 3 + j) * PFB_HIST_STRIDE;
+    for (int i = threadIdx.x; i < PB_NFFT / 4; i += blockDim.x) ((uint32_t *)dst)[i] = ((const uint32_t *)src)[i];
+    if (pol == 0 && threadIdx.x < PB_BLK_PER_FFT)
+        hflags[((size_t)ant * 3 + j) * PB_BLK_PER_FFT + threadIdx.x] =
+            flags[(size_t)ant * flags_ant_stride + (size_t)rr * PB_BLK_PER_FFT + threadIdx.x];
+    if (pol == 0 && threadIdx.x == 0) hvalid[ant * 3 + j] = 1;
+}
+
+hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now)
+{
+    const int nrows = nseg * h->R;
+    if (h->cfg.rfi_mode) {
+        dim3 g((nrows + 255) / 256, h->A);
+        k_pfb_weights<<<g, 256, 0, h->stream>>>(h->d_flags, (size_t)h->S * h->nblk_seg, h->d_hist_flags, h->d_tapE,
+                                                h->d_wrow, (size_t)h->S * h->R, nrows);
+    }
+    PfbArgs a;
+    a.in = h->d_in;
+    a.in_ant_stride = (size_t)h->S * 2 * h->seg_samples;
+    a.seg_samples = h->seg_samples;
+    a.hist = h->d_hist_in;
+    a.flags = h->d_flags;
+    a.flags_ant_stride = (size_t)h->S * h->nblk_seg;
+    a.hflags = h->d_hist_flags;
+    a.hvalid = h->d_hist_valid;
+    a.wrow = h->d_wrow;
+    a.wrow_ant_stride = (size_t)h->S * h->R;
+    a.fir = h->ft.taps;
+    a.Praw = h->d_Praw;
+    a.Pkur = h->d_Pkur;
+    a.p_ant_stride = (size_t)h->S * 2 * h->R * PB_NCHANOUT;
+    a.tw2 = h->ft.tw2;
+    a.tw3 = h->ft.tw3;
+    a.postc = h->ft.postc;
+    a.frb.delays = (inject_now > 0) ? h->d_frb_delays : nullptr;
+    a.frb.width = h->frb_width;
+    a.frb.amp = h->frb_amp;
+    a.frb.since = 0;
+    a.R = h->R;
+    a.rfi_mode = h->cfg.rfi_mode;
+    a.inject_now = inject_now;
+    dim3 grid((unsigned)nrows, h->cfg.rfi_mode == 2 ? 4 : 2, (unsigned)h->A);
+    k_channelize_pfb<<<grid, 256, 0, h->stream>>>(a);
+    dim3 gh(3, 2, h->A);
+    k_pfb_history<<<gh, 256, 0, h->stream>>>(h->d_in, a.in_ant_stride, h->seg_samples, h->d_flags, a.flags_ant_stride,
+                                             h->d_hist_in, h->d_hist_flags, h->d_hist_valid, h->R, nrows);
+    return hipGetLastError();
+}

@@ -254,6 +254,34 @@ static int create_impl(pb_handle *h)
     }
     int rc = build_fft_tables(h);
     if (rc) return rc;
+    if (c.taps == 4) {
+        const size_t hb = A * 2 * 3 * 12512;
+        HIPCHK(h, dmalloc(h, &h->d_hist_in, hb));
+        HIPCHK(h, hipMemset(h->d_hist_in, 0, hb));
+        HIPCHK(h, dmalloc(h, &h->d_hist_flags, A * 3 * PB_BLK_PER_FFT));
+        HIPCHK(h, hipMemset(h->d_hist_flags, 1, A * 3 * PB_BLK_PER_FFT));
+        HIPCHK(h, dmalloc(h, &h->d_hist_valid, A * 3));
+        HIPCHK(h, hipMemset(h->d_hist_valid, 0, A * 3));
+        // window energy per (tap, 500-sample block), from the float taps the kernel multiplies by
+        std::vector<float> taps((size_t)4 * PB_NFFT), E(101);
+        HIPCHK(h, hipMemcpy(taps.data(), h->ft.taps, taps.size() * sizeof(float), hipMemcpyDeviceToHost));
+        double tot = 0;
+        for (int j = 0; j < 4; ++j)
+            for (int b = 0; b < PB_BLK_PER_FFT; ++b) {
+                double e = 0;
+                for (int m = 0; m < PB_NKURTO; ++m) {
+                    const double t = taps[(size_t)j * PB_NFFT + b * PB_NKURTO + m];
+                    e += t * t;
+                }
+                E[j * PB_BLK_PER_FFT + b] = (float)e;
+            }
+        float totf = 0.f;
+        for (int i = 0; i < 100; ++i) totf = totf + E[i];      // same order as k_pfb_weights sums
+        (void)tot;
+        E[100] = totf;
+        HIPCHK(h, dmalloc(h, &h->d_tapE, (size_t)101));
+        HIPCHK(h, hipMemcpy(h->d_tapE, E.data(), 101 * sizeof(float), hipMemcpyHostToDevice));
+    }
     h->dag = make_dag((float)PB_NKURTO);
     return PB_OK;
 }
@@ -296,6 +324,8 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
     h->vdif_cap = 0;
     h->d_wrow = h->d_stats = h->d_fraw = h->d_fkur = h->d_Praw = h->d_Pkur = h->d_bp = h->d_ave = nullptr;
     h->d_frb_delays = nullptr;
+    h->d_hist_in = h->d_hist_flags = h->d_hist_valid = nullptr;
+    h->d_tapE = nullptr;
     h->frb_width = 0.f;
     h->frb_amp = 1.f;
     h->d_Xraw = h->d_Xkur = nullptr;
@@ -349,7 +379,8 @@ extern "C" void pb_destroy(pb_handle *h)
             if (p) (void)hipFree(p);
         if (h->h_codes) (void)hipHostFree(h->h_codes);
     }
-    void *ptrs[] = {h->d_vdif, h->d_frame_idx, h->d_bp, h->d_frb_delays, h->ft.w25, h->ft.w10, h->ft.tw2,
+    void *ptrs[] = {h->d_vdif, h->d_frame_idx, h->d_bp, h->d_frb_delays, h->d_hist_in, h->d_hist_flags,
+                    h->d_hist_valid, h->d_tapE, h->ft.w25, h->ft.w10, h->ft.tw2,
                     h->ft.tw3, h->ft.post, h->ft.postc, h->ft.taps};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -436,6 +467,19 @@ extern "C" int pb_reset_bandpass(pb_handle *h, int ant)
     if (check_ant(h, ant)) return PB_EINVAL;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipMemsetAsync(h->d_bp + (size_t)ant * 4 * PB_NCHANOUT, 0, 4 * PB_NCHANOUT * sizeof(float), h->stream));
+    return PB_OK;
+}
+
+extern "C" int pb_reset_history(pb_handle *h, int ant)
+{
+    if (!h) return PB_EINVAL;
+    if (check_ant(h, ant)) return PB_EINVAL;
+    if (h->cfg.taps != 4) return PB_OK;           // only the PFB window carries rows across calls
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, sync_all(h));
+    HIPCHK(h, hipMemset(h->d_hist_in + (size_t)ant * 2 * 3 * 12512, 0, (size_t)2 * 3 * 12512));
+    HIPCHK(h, hipMemset(h->d_hist_flags + (size_t)ant * 3 * PB_BLK_PER_FFT, 1, 3 * PB_BLK_PER_FFT));
+    HIPCHK(h, hipMemset(h->d_hist_valid + (size_t)ant * 3, 0, 3));
     return PB_OK;
 }
 
@@ -684,7 +728,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         }
     } else {
         StageTimer t(h, PB_ST_CHANNELIZE);
-        HIPCHK(h, launch_channelize(h, nseg, inject_now));
+        HIPCHK(h, h->cfg.taps == 4 ? launch_channelize_pfb(h, nseg, inject_now) : launch_channelize(h, nseg, inject_now));
         t.stop();
     }
     HIPCHK(h, hipEventRecord(h->ev_fftdone, h->stream));

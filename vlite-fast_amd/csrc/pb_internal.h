@@ -64,6 +64,10 @@ struct pb_handle {
     uint8_t *d_codes;      // [A][2 streams][S][trim]
     float *d_ave;          // [A][2 streams][S][ave_per_seg]
     float *d_frb_delays;   // [6251]
+    uint8_t *d_hist_in;    // taps=4: [A][2][3][12512] last three rows of the previous batch
+    uint8_t *d_hist_flags; // taps=4: [A][3][25] their kurtosis flags (1 = flagged / no data)
+    uint8_t *d_hist_valid; // taps=4: [A][3] slot holds data
+    float *d_tapE;         // taps=4: [4][25] window energy per (tap, block) + total at [100]
     float frb_width, frb_amp;   // inject_frb parameters (rows, amplitude factor)
     // --- pipeline slots: the d_* buffers above (except d_bp, d_vdif, tables) exist once per
     // set; the members above always alias the SELECTED set (pb_select_set)
@@ -108,6 +112,7 @@ hipError_t launch_inject_c64(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_detect(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_detect_pow(pb_handle *h, int nseg);
 hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now);
+hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_channelize_f32(pb_handle *h, const float *d_x, int nrows, int taps, float2 *d_out);
 hipError_t launch_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate);
 hipError_t launch_coadd_digitise(pb_handle *h, int nseg, const float *d_sum, float scale,

@@ -50,7 +50,7 @@ class PbTimers(C.Structure):
 
 
 EXPORTS = ["pb_config_default", "pb_create", "pb_destroy", "pb_last_error", "pb_query",
-           "pb_set_stream", "pb_sync", "pb_reset_bandpass", "pb_get_bandpass", "pb_set_bandpass",
+           "pb_set_stream", "pb_sync", "pb_reset_bandpass", "pb_reset_history", "pb_get_bandpass", "pb_set_bandpass",
            "pb_submit_planar", "pb_submit_planar_dev", "pb_submit_vdif", "pb_input_dev", "pb_process", "pb_set_frb_params", "pb_select_set", "pb_fetch", "pb_fetch_ptr",
            "pb_output_dev", "pb_coadd_local", "pb_coadd_finish", "pb_coadd_fetch_ptr", "pb_profile", "pb_get_timers",
            "pb_debug_fetch", "pb_channelize_f32", "pb_version"]
@@ -88,6 +88,7 @@ def load():
     L.pb_set_stream.argtypes = [vp, vp]
     L.pb_sync.argtypes = [vp]
     L.pb_reset_bandpass.argtypes = [vp, C.c_int]
+    L.pb_reset_history.argtypes = [vp, C.c_int]
     L.pb_get_bandpass.argtypes = [vp, C.c_int, fp, fp]
     L.pb_set_bandpass.argtypes = [vp, C.c_int, fp, fp]
     L.pb_submit_planar.argtypes = [vp, C.c_int, C.c_int, u8p, u8p, C.c_size_t]
@@ -245,6 +246,9 @@ class PbHandle(object):
 
     def reset_bandpass(self, ant):
         self._chk(self._L.pb_reset_bandpass(self._h, ant))
+
+    def reset_history(self, ant):
+        self._chk(self._L.pb_reset_history(self._h, ant))
 
     def get_bandpass(self, ant):
         r = np.empty((2, NCHANOUT), np.float32)

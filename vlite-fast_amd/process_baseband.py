@@ -181,6 +181,7 @@ def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None):
         t_obs = time.time()
         hdr = vdif.ascii_header_parse(raw_hdr)
         log("INFO", "Beginning new observation.")
+        handle.reset_history(0)          # taps=4: the FIR window does not span observations
         block = np.empty(sec_bytes, np.uint8)
         first = in_ring.read(vdif.VD_FRM)
         if len(first) != vdif.VD_FRM:
