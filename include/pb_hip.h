@@ -186,6 +186,23 @@ int pb_debug_fetch(pb_handle *h, int what, int ant, int seg, void *dst, size_t n
  * out is nrows x 6251 complex64 (interleaved re,im). */
 int pb_channelize_f32(pb_handle *h, const float *x, int nrows, int taps, float *out);
 
+/* ---- downstream search (replaces the external heimdall for BASELINE config 5) ----
+ * Brute-force incoherent dedispersion over a linear DM grid + boxcar matched filter on a block of
+ * filterbank codes (SIGPROC order [time][channel], 8/4/2 bit).  Delay constant 4.148808e3 MHz^2 s
+ * (src/candidate.py:33); reference = top of the band.  zap_ranges: nzap pairs [lo, hi) of channels
+ * to ignore (heimdall's -zap_chans).  Parity with heimdall: unpinned (third-party, absent). */
+typedef struct pb_search pb_search;
+int pb_search_create(int device, int nchan, int max_samples, float fch1_mhz, float foff_mhz, float tsamp_s,
+                     float dm_min, float dm_max, float dm_step, int boxcar_max, const int *zap_ranges,
+                     int nzap, pb_search **out);
+void pb_search_destroy(pb_search *s);
+const char *pb_search_last_error(const pb_search *s);
+int pb_search_info(const pb_search *s, int *ndm, int *nbox, int *max_delay);
+/* outputs (host; any may be NULL): snr / width_log2 / series are [ndm][tout], tout = nsamp - max_delay;
+ * stats is [ndm][2] = clipped mean and rms of each dedispersed series */
+int pb_search_run(pb_search *s, const void *codes, int codes_on_device, int nsamp, int nbit, float *snr,
+                  uint8_t *width_log2, uint32_t *series, float *stats, int *tout);
+
 const char *pb_version(void);
 
 #ifdef __cplusplus

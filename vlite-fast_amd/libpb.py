@@ -53,7 +53,8 @@ EXPORTS = ["pb_config_default", "pb_create", "pb_destroy", "pb_last_error", "pb_
            "pb_set_stream", "pb_sync", "pb_reset_bandpass", "pb_reset_history", "pb_get_bandpass", "pb_set_bandpass",
            "pb_submit_planar", "pb_submit_planar_dev", "pb_submit_vdif", "pb_input_dev", "pb_process", "pb_set_frb_params", "pb_select_set", "pb_fetch", "pb_fetch_ptr",
            "pb_output_dev", "pb_coadd_local", "pb_coadd_finish", "pb_coadd_fetch_ptr", "pb_profile", "pb_get_timers",
-           "pb_debug_fetch", "pb_channelize_f32", "pb_version"]
+           "pb_debug_fetch", "pb_channelize_f32", "pb_version", "pb_search_create", "pb_search_destroy",
+           "pb_search_last_error", "pb_search_info", "pb_search_run"]
 
 _lib = None
 
@@ -109,6 +110,15 @@ def load():
     L.pb_debug_fetch.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
     L.pb_channelize_f32.argtypes = [vp, fp, C.c_int, C.c_int, fp]
     L.pb_version.restype = C.c_char_p
+    ip = C.POINTER(C.c_int)
+    L.pb_search_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, C.c_int, ip, C.c_int, C.POINTER(vp)]
+    L.pb_search_destroy.argtypes = [vp]
+    L.pb_search_destroy.restype = None
+    L.pb_search_last_error.argtypes = [vp]
+    L.pb_search_last_error.restype = C.c_char_p
+    L.pb_search_info.argtypes = [vp, ip, ip, ip]
+    L.pb_search_run.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, fp, u8p, C.POINTER(C.c_uint32), fp, ip]
     for n in EXPORTS:
         f = getattr(L, n)
         if f.restype is C.c_int or n in ("pb_create", "pb_query", "pb_sync"):

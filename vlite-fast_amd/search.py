@@ -1,0 +1,115 @@
+"""Dedispersion + boxcar search on a filterbank block, and heimdall-style candidate lines.
+
+Stands where the external `heimdall_stream` stands in the reference's chain
+(/root/reference/scripts/start_heimdall_single_antenna:21; candidate line columns
+`S/N, peak_idx, peak_time, tfilt, dmi, dm, ngiant, i0, i1` as parsed by src/candidate.py:8-18).
+The GPU work is libpb_hip.so's pb_search_* (csrc/pb_search.hip); this module only drives it and
+groups the above-threshold samples into candidates on the host.  heimdall is third-party and not in
+the image: its DM spacing, baseline removal and giant merging are not reproduced -- parity with its
+candidate list is unpinned.
+"""
+import ctypes as C
+import importlib
+
+import numpy as np
+
+_pkg = __package__ or "vlite-fast_amd"
+
+# heimdall flags of the reference's production launch
+HEIMDALL_DM = (2.0, 1000.0)
+HEIMDALL_BOXCAR_MAX = 64
+HEIMDALL_GULP = 30720
+HEIMDALL_ZAP = ((0, 190), (3900, 4096))
+FCH1 = 384 + (2155 - 0.5) * (-64. / 6251)     # MHz, src/process_baseband.cu:261
+FOFF = -64. / 6251
+TSAMP = 12500.0 / 128e6 * 8
+
+
+class Searcher(object):
+    def __init__(self, device=0, nchan=4096, max_samples=HEIMDALL_GULP, fch1=FCH1, foff=FOFF, tsamp=TSAMP,
+                 dm_min=HEIMDALL_DM[0], dm_max=HEIMDALL_DM[1], dm_step=2.0, boxcar_max=HEIMDALL_BOXCAR_MAX,
+                 zap=HEIMDALL_ZAP):
+        lp = importlib.import_module(_pkg + ".libpb")
+        self._lp = lp
+        self._L = lp.load()
+        zr = (C.c_int * (2 * len(zap)))(*[v for pair in zap for v in pair])
+        self._s = C.c_void_p()
+        rc = self._L.pb_search_create(device, nchan, max_samples, fch1, foff, tsamp, dm_min, dm_max, dm_step,
+                                      boxcar_max, zr, len(zap), C.byref(self._s))
+        if rc != 0:
+            raise lp.PbError("pb_search_create failed (%d): %s" % (rc, self._L.pb_search_last_error(None).decode()))
+        ndm, nbox, md = C.c_int(), C.c_int(), C.c_int()
+        self._L.pb_search_info(self._s, C.byref(ndm), C.byref(nbox), C.byref(md))
+        self.ndm, self.nbox, self.max_delay = ndm.value, nbox.value, md.value
+        self.nchan, self.tsamp = nchan, tsamp
+        self.dms = dm_min + dm_step * np.arange(self.ndm)
+
+    def close(self):
+        if getattr(self, "_s", None):
+            self._L.pb_search_destroy(self._s)
+            self._s = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, codes, nbit=8, want_series=False):
+        """codes: uint8 array holding nsamp x nchan samples of nbit bits (SIGPROC order).
+        Returns dict(snr [ndm][tout] f32, width_log2 [ndm][tout] u8, stats [ndm][2], series?)."""
+        codes = np.ascontiguousarray(codes, np.uint8).ravel()
+        nsamp = codes.size * (8 // nbit) // self.nchan
+        tout = nsamp - self.max_delay
+        if tout < 64:
+            raise ValueError("block shorter than the largest dispersion delay (%d samples)" % self.max_delay)
+        snr = np.empty((self.ndm, tout), np.float32)
+        wid = np.empty((self.ndm, tout), np.uint8)
+        stats = np.empty((self.ndm, 2), np.float32)
+        series = np.empty((self.ndm, tout), np.uint32) if want_series else None
+        t = C.c_int()
+        rc = self._L.pb_search_run(self._s, codes.ctypes.data_as(C.c_void_p), 0, nsamp, nbit,
+                                   snr.ctypes.data_as(C.POINTER(C.c_float)), wid.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                   series.ctypes.data_as(C.POINTER(C.c_uint32)) if want_series else None,
+                                   stats.ctypes.data_as(C.POINTER(C.c_float)), C.byref(t))
+        if rc != 0:
+            raise self._lp.PbError("pb_search_run failed (%d): %s" % (rc, self._L.pb_search_last_error(self._s).decode()))
+        return dict(snr=snr, width_log2=wid, stats=stats, series=series, tout=tout)
+
+
+def find_candidates(snr, width_log2, dms, tsamp, threshold=6.0, dm_tol=0.1, sample0=0):
+    """Group above-threshold (dm, t) samples into candidates: strongest first, a candidate absorbs
+    every sample that overlaps it in time and lies within dm_tol (fractional) in DM -- the overlap
+    rule of the reference's coincidencer (src/candidate.py:49-65).  Returns a list of dicts with
+    heimdall's columns."""
+    idm, it = np.nonzero(snr >= threshold)
+    if idm.size == 0:
+        return []
+    s = snr[idm, it]
+    w = (1 << width_log2[idm, it].astype(np.int64))
+    order = np.argsort(-s)
+    idm, it, s, w = idm[order], it[order], s[order], w[order]
+    taken = np.zeros(idm.size, bool)
+    cands = []
+    for k in range(idm.size):
+        if taken[k]:
+            continue
+        i0, i1, dm = it[k], it[k] + w[k], dms[idm[k]]
+        near = (~taken) & (it < i1) & (it + w > i0) & (np.abs(dms[idm] - dm) <= dm_tol * max(dm, 1.0) + 1e-9)
+        taken |= near
+        cands.append(dict(snr=float(s[k]), peak_idx=int(sample0 + it[k]), peak_time=float((sample0 + it[k]) * tsamp),
+                          tfilt=int(np.log2(w[k])), dmi=int(idm[k]), dm=float(dm), ngiant=int(near.sum()),
+                          i0=int(sample0 + it[near].min()), i1=int(sample0 + (it[near] + w[near]).max())))
+    return cands
+
+
+def candidate_line(c):
+    """One heimdall-format text line (columns of src/candidate.py:8-18)."""
+    return "%.6f\t%d\t%.6f\t%d\t%d\t%.4f\t%d\t%d\t%d" % (c["snr"], c["peak_idx"], c["peak_time"], c["tfilt"],
+                                                        c["dmi"], c["dm"], c["ngiant"], c["i0"], c["i1"])
