@@ -12,5 +12,7 @@ Only the hot path of the reference's process_baseband executable lives here:
   process_baseband.py   the executable's host side, same command-line flags
   genbase.py       genbase-style synthetic baseband (test-side producer)
   coadd.py         incoherent antenna sum across GPUs (torch.distributed / RCCL)
+  search.py        dedispersion + boxcar search on the filterbank (stands where heimdall stands)
+  triggers.py      trigger_t wire format towards the voltage dumper
 """
 __version__ = "0.1"
