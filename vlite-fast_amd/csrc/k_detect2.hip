@@ -38,7 +38,9 @@ struct Detect2Args {
     float scale, oms, tscale;
 };
 
-#define D2_DEPTH 4                 // chunks of power loads in flight per workgroup
+#define D2_DEPTH 2                 // chunks of power loads in flight per workgroup: 4 slots x 8 KB + 16 KB
+                                   // = 48 KB of LDS, so that a detect workgroup fits beside two channeliser
+                                   // workgroups of the next batch (deeper rings measured no faster)
 #define D2_NSLOT (D2_DEPTH + 2)    // LDS ring slots (a slot is re-filled two barriers after its last reader)
 
 template <int N> __device__ __forceinline__ void wait_vmcnt()

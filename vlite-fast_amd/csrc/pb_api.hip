@@ -3,6 +3,7 @@
 // the D2H side.  No CPU fallback exists: every entry point needs a HIP device.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "pb_internal.h"
@@ -697,6 +698,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         hipError_t e = hipSuccess;
         if (overlap) {
             e = hipStreamWaitEvent(h->s_kur, h->ev_fftdone, 0);
+            if (e == hipSuccess) e = hipStreamWaitEvent(h->s_kur, h->ev_det, 0);   // flags / weights of this set free
             h->stream = h->s_kur;
         } else if (h->sets.size() >= 2) {
             // staging went to s_kur: the main stream must see it
@@ -733,9 +735,36 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
     }
     HIPCHK(h, hipEventRecord(h->ev_fftdone, h->stream));
     h->last_set = h->cur_set;
-    // All kernels stay on ONE stream: they are VALU-issue bound, so running detect beside the next
-    // batch's channeliser only stretches both (measured, profiles/r01_notes.md).  Only the D2H of the
-    // filterbank bytes goes to the second stream (copy engine), overlapping the next batch's kernels.
+    // With two or more buffer sets, detect + D2H of this batch run on the second stream so that they
+    // overlap the NEXT batch's kurtosis and channeliser.  Detect is latency-bound on its serial
+    // bandpass wave (one 48 KB workgroup per CU), the channeliser VALU-bound: side by side the step is
+    // ~9 % shorter than back to back (0.915 vs 1.007 ms per second of data; PB_OVERLAP_DETECT=0 turns
+    // it off).  With one buffer set everything stays on one stream.
+    static const int overlap_detect = getenv("PB_OVERLAP_DETECT") ? atoi(getenv("PB_OVERLAP_DETECT")) : 1;
+    if (overlap_detect && h->sets.size() >= 2 && !hipfft) {
+        hipStream_t s_main = h->stream;
+        hipError_t e2 = hipStreamWaitEvent(h->s_det, h->ev_fftdone, 0);
+        h->stream = h->s_det;
+        if (e2 == hipSuccess) {
+            StageTimer t(h, PB_ST_DETECT);
+            e2 = launch_detect(h, nseg, inject_now);
+            t.stop();
+        }
+        for (int a = 0; a < h->A && e2 == hipSuccess; ++a)
+            for (int st = 0; st < 2 && e2 == hipSuccess; ++st) {
+                if (st == 0 ? h->cfg.rfi_mode == 1 : h->cfg.rfi_mode == 0) continue;
+                const size_t o = ((size_t)a * 2 + st) * h->S * h->trim;
+                e2 = hipMemcpyAsync(h->h_codes + o, h->d_codes + o, (size_t)nseg * h->trim,
+                                    hipMemcpyDeviceToHost, h->s_det);
+            }
+        if (e2 == hipSuccess) e2 = hipEventRecord(h->ev_det, h->s_det);
+        if (e2 == hipSuccess) e2 = hipEventRecord(h->ev_alldone, h->s_det);
+        h->stream = s_main;
+        HIPCHK(h, e2);
+        h->processed = nseg;
+        h->sets[h->cur_set].processed = nseg;
+        return PB_OK;
+    }
     {
         StageTimer t(h, PB_ST_DETECT);
         HIPCHK(h, launch_detect(h, nseg, inject_now));
