@@ -13,11 +13,10 @@
 // oracle/pb_oracle.c "K6"; results agree with the oracle bit for bit.  Pass-1 butterfly input
 // r comes from 500-sample kurtosis block r, so a flagged block is simply a zeroed input.
 //
-// Workgroup roles (rfi_mode 2): the "raw" workgroup of a row transforms the unflagged data and
-// writes the raw power plane -- and, when the row has no flagged block, the excised plane as
-// well (same spectrum, divided by the row weight); the "excised" workgroup exits at once in
-// that case, writes +inf ("no data") if every block is flagged, and otherwise transforms the
-// zeroed data.
+// Passes (rfi_mode 2): every (row, pol) workgroup transforms the unflagged data and writes the raw
+// power plane -- and, when the row has no flagged block, the excised plane as well (same spectrum,
+// divided by the row weight).  Only when some block is flagged does it run a second pass on the
+// zeroed data (or write +inf, "no data", if every block is flagged).
 //
 // LDS: one 6250 x float2 buffer (50 000 B) used in place: every pass reads its inputs into
 // registers, barriers, then writes.  3 workgroups per CU.
@@ -43,45 +42,12 @@ struct ChanArgs {
     int R, rfi_mode, inject_now;
 };
 
-// Three workgroups per CU (LDS 3 x 50 000 B, <= 168 VGPRs).  Measured: capping residency at two
-// to let a detect workgroup of the previous batch co-reside does not pay -- both kernels are
-// bound by VALU issue, so running them side by side only stretches each (profiles/r01 notes).
-__global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
+// One transform of one (row, pol): ROLE 0 = raw spectrum (also fills the excised plane when the row
+// has no flagged block), ROLE 1 = excised spectrum (flagged blocks zeroed).
+template <int ROLE>
+__device__ __forceinline__ void channelize_pass(const ChanArgs &a, float2 *buf, int tid, int seg, int row, int pol,
+                                                int ant, unsigned mask, float wrow, size_t prow)
 {
-    __shared__ float2 buf[M_HALF];
-    const int tid = threadIdx.x;
-    const int grow = blockIdx.x;  // seg * R + row
-    const int pol = blockIdx.y & 1, ant = blockIdx.z;
-    // role: 0 = raw spectrum (+ excised plane when nothing is flagged), 1 = excised spectrum
-    const int role = a.rfi_mode == 2 ? (blockIdx.y >> 1) : (a.rfi_mode == 1 ? 1 : 0);
-    const int seg = grow / a.R, row = grow % a.R;
-
-    unsigned mask = 0;
-    if (a.rfi_mode) {
-        // every lane reads the 25 flag bytes of the row (uniform addresses -> scalar loads)
-        const uint8_t *f = a.flags + (size_t)ant * a.flags_ant_stride + (size_t)grow * PB_BLK_PER_FFT;
-#pragma unroll
-        for (int r = 0; r < PB_BLK_PER_FFT; ++r) mask |= (f[r] ? 1u : 0u) << r;
-        mask = __builtin_amdgcn_readfirstlane(mask);
-    }
-    const bool all_bad = mask == 0x1ffffffu;
-    if (a.rfi_mode == 2 && role == 1 && mask == 0) return;  // the raw workgroup writes both planes
-
-    // row weight exactly as apply_kurtosis accumulates it: one 500/12500 per unflagged block
-    float wrow = 0.f;
-    {
-        const float inc = (float)PB_NKURTO / PB_NFFT;
-        const int good = PB_BLK_PER_FFT - __popc(mask);
-        for (int i = 0; i < good; ++i) wrow = wrow + inc;
-    }
-    const size_t prow = (size_t)ant * a.p_ant_stride + (((size_t)seg * 2 + pol) * a.R + row) * PB_NCHANOUT;
-    if (role == 1 && all_bad) {
-        // weight 0: the row's excised power is never used for its value (detect_and_normalize3
-        // :474-476 writes 0 and leaves the bandpass alone); +inf makes the detect kernel's clip test
-        // do exactly that without having to look at the weight
-        for (int c = tid; c < PB_NCHANOUT; c += 256) a.Pkur[prow + c] = __builtin_inff();
-        return;
-    }
 
     // Stage the row's 12500 bytes in LDS with 16-byte loads (narrow per-lane loads are bound by
     // the address unit, not by HBM: 2-byte loads move 128 B per wave instruction, these 1 KiB),
@@ -107,7 +73,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
     __syncthreads();
     float2 v[25];
     if (tid < 250) {
-        const unsigned zmask = role == 1 ? mask : 0u;
+        const unsigned zmask = ROLE == 1 ? mask : 0u;
         const uint16_t *sb = (const uint16_t *)((const uint8_t *)buf + o);
 #pragma unroll
         for (int r = 0; r < 25; ++r) {
@@ -122,8 +88,8 @@ __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
     // FRB injection window of this row, per channel (inject_frb :361-380)
     const bool inject = a.frb.delays != nullptr && a.inject_now > 0;
     const int since = inject ? (a.inject_now - 1 + seg) * a.R : 0;
-    const bool also_kur = a.rfi_mode == 2 && role == 0 && mask == 0;
-    float *P0 = (role == 1 ? a.Pkur : a.Praw) + prow;
+    const bool also_kur = a.rfi_mode == 2 && ROLE == 0 && mask == 0;
+    float *P0 = (ROLE == 1 ? a.Pkur : a.Praw) + prow;
     float *P1 = a.Pkur + prow;
     // four consecutive channels per thread: 16-byte twiddle loads and 16-byte power stores
     for (int c4 = tid * 4; c4 < PB_NCHANOUT; c4 += 1024) {
@@ -157,11 +123,62 @@ __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
         }
         // the excised plane carries pow / w (detect_and_normalize3 :452,:481), so that the
         // serial bandpass recurrence downstream has no division in it
-        if (role == 0) *(float4 *)(P0 + c4) = make_float4(pw[0], pw[1], pw[2], pw[3]);
-        if (role == 1 || also_kur)
-            *(float4 *)((role == 1 ? P0 : P1) + c4) =
+        if (ROLE == 0) *(float4 *)(P0 + c4) = make_float4(pw[0], pw[1], pw[2], pw[3]);
+        if (ROLE == 1 || also_kur)
+            *(float4 *)((ROLE == 1 ? P0 : P1) + c4) =
                 make_float4(pw[0] / wrow, pw[1] / wrow, pw[2] / wrow, pw[3] / wrow);
     }
+}
+
+// Three workgroups per CU (LDS 3 x 50 000 B, <= 168 VGPRs).  Measured: capping residency at two
+// to let a detect workgroup of the previous batch co-reside does not pay -- both kernels are
+// bound by VALU issue, so running them side by side only stretches each (profiles/r01 notes).
+__global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
+{
+    __shared__ float2 buf[M_HALF];
+    int tid = threadIdx.x;
+    const int grow = blockIdx.x;  // seg * R + row
+    const int pol = blockIdx.y, ant = blockIdx.z;
+    const int seg = grow / a.R, row = grow % a.R;
+
+    unsigned mask = 0;
+    if (a.rfi_mode) {
+        // every lane reads the 25 flag bytes of the row (uniform addresses -> scalar loads)
+        const uint8_t *f = a.flags + (size_t)ant * a.flags_ant_stride + (size_t)grow * PB_BLK_PER_FFT;
+#pragma unroll
+        for (int r = 0; r < PB_BLK_PER_FFT; ++r) mask |= (f[r] ? 1u : 0u) << r;
+        mask = __builtin_amdgcn_readfirstlane(mask);
+    }
+    const bool all_bad = mask == 0x1ffffffu;
+    // passes of this workgroup: role 0 = raw spectrum (also fills the excised plane when the row has
+    // no flagged block), role 1 = excised spectrum (only when some block is flagged: 13 % of rows on
+    // clean noise).  One workgroup per (row, pol) does both, instead of launching a second grid of
+    // workgroups of which 87 % would exit at once.
+    const int role_first = a.rfi_mode == 1 ? 1 : 0;
+    const int role_last = a.rfi_mode == 0 ? 0 : ((a.rfi_mode == 2 && mask == 0) ? 0 : 1);
+
+    // row weight exactly as apply_kurtosis accumulates it: one 500/12500 per unflagged block
+    float wrow = 0.f;
+    {
+        const float inc = (float)PB_NKURTO / PB_NFFT;
+        const int good = PB_BLK_PER_FFT - __popc(mask);
+        for (int i = 0; i < good; ++i) wrow = wrow + inc;
+    }
+    const size_t prow = (size_t)ant * a.p_ant_stride + (((size_t)seg * 2 + pol) * a.R + row) * PB_NCHANOUT;
+    if (a.rfi_mode != 1) channelize_pass<0>(a, buf, tid, seg, row, pol, ant, mask, wrow, prow);
+    if (a.rfi_mode == 0 || (a.rfi_mode == 2 && mask == 0)) return;
+    if (all_bad) {
+        // weight 0: the row's excised power is never used for its value (detect_and_normalize3
+        // :474-476 writes 0 and leaves the bandpass alone); +inf makes the detect kernel's clip test
+        // do exactly that without having to look at the weight
+        for (int c = tid; c < PB_NCHANOUT; c += 256) a.Pkur[prow + c] = __builtin_inff();
+        return;
+    }
+    if (a.rfi_mode == 2) {
+        __syncthreads();   // the raw pass has finished reading buf
+        asm volatile("" : "+v"(tid));   // no sharing of tid-derived addresses across the two passes
+    }
+    channelize_pass<1>(a, buf, tid, seg, row, pol, ant, mask, wrow, prow);
 }
 
 static bool check_consts(std::string &why)
@@ -213,7 +230,7 @@ hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now)
     a.R = h->R;
     a.rfi_mode = h->cfg.rfi_mode;
     a.inject_now = inject_now;
-    dim3 grid((unsigned)(nseg * h->R), h->cfg.rfi_mode == 2 ? 4 : 2, (unsigned)h->A);
+    dim3 grid((unsigned)(nseg * h->R), 2, (unsigned)h->A);
     k_channelize<<<grid, 256, 0, h->stream>>>(a);
     return hipGetLastError();
 }
