@@ -15,53 +15,90 @@ constexpr float kW25[25][2] = FC_W25_INIT;
 constexpr float kW10[5][2] = FC_W10_INIT;
 }
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 w)
+// Complex values live in aligned VGPR pairs (re, im) so that the butterflies are packed-f32
+// instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two IEEE operations per lane per issue,
+// each rounding exactly like its scalar form).  Swaps and sign flips of halves fold into the
+// instructions' op_sel / neg modifiers.  The arithmetic is element for element the oracle's.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ f2 pkfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// The shuffled forms below are written as instructions because the compiler spends two extra moves
+// on each instead of using the source-half selectors:
+//   op_sel[i] / op_sel_hi[i]: which half of source i feeds the low / high result (0 = low half)
+//   neg_lo[i] / neg_hi[i]:    negate source i in the low / high result
+// Independent operations share one asm block so that no instruction consumes its predecessor's
+// result (the compiler pads a dependent pair of asm statements with s_nop, 4 cycles each).
+
+// y_minus = m - i n = m + (n.y, -n.x),  y_plus = m + i n = m - (n.y, -n.x), for two (m, n) pairs
+__device__ __forceinline__ void rot4(f2 m1, f2 n1, f2 m2, f2 n2, f2 &y1, f2 &y4, f2 &y2, f2 &y3)
 {
-    const float t1 = a.y * w.y;
-    const float re = __builtin_fmaf(a.x, w.x, -t1);
-    const float t2 = a.y * w.x;
-    const float im = __builtin_fmaf(a.x, w.y, t2);
-    return make_float2(re, im);
+    asm("v_pk_add_f32 %0, %4, %5 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %4, %5 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %2, %6, %7 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %3, %6, %7 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"
+        : "=&v"(y1), "=&v"(y4), "=&v"(y2), "=&v"(y3)
+        : "v"(m1), "v"(n1), "v"(m2), "v"(n2));
 }
 
-__device__ __forceinline__ void dft5(float2 v0, float2 v1, float2 v2, float2 v3, float2 v4,
-                                     float2 &y0, float2 &y1, float2 &y2, float2 &y3, float2 &y4)
+// a *= w, complex: (a.x w.x - a.y w.y, a.x w.y + a.y w.x) evaluated as
+// t = a.y * (w.y, w.x);  a = fma(a.x, (w.x, w.y), (-t.x, t.y))      [oracle cmul]
+#define PB_CMUL_MUL(t, a, w) "v_pk_mul_f32 " t ", " a ", " w " op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+#define PB_CMUL_FMA(t, a, w) "v_pk_fma_f32 " a ", " a ", " w ", " t " op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"
+#define PB_CMUL4_BODY                                                                               \
+    PB_CMUL_MUL("%4", "%0", "%8") PB_CMUL_MUL("%5", "%1", "%9") PB_CMUL_MUL("%6", "%2", "%10")      \
+    PB_CMUL_MUL("%7", "%3", "%11") PB_CMUL_FMA("%4", "%0", "%8") PB_CMUL_FMA("%5", "%1", "%9")      \
+    PB_CMUL_FMA("%6", "%2", "%10") PB_CMUL_FMA("%7", "%3", "%11")
+// four at a time, twiddles in vector registers
+__device__ __forceinline__ void cmul4(f2 &a0, f2 &a1, f2 &a2, f2 &a3, f2 w0, f2 w1, f2 w2, f2 w3)
+{
+    f2 t0, t1, t2, t3;
+    asm(PB_CMUL4_BODY
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+}
+// four at a time, compile-time twiddles in scalar register pairs
+__device__ __forceinline__ void cmul4_k(f2 &a0, f2 &a1, f2 &a2, f2 &a3, f2 w0, f2 w1, f2 w2, f2 w3)
+{
+    f2 t0, t1, t2, t3;
+    asm(PB_CMUL4_BODY
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "s"(w0), "s"(w1), "s"(w2), "s"(w3));
+}
+// one, twiddle in vector registers (the compiler schedules other work between the two halves)
+__device__ __forceinline__ f2 cmul(f2 a, f2 w)
+{
+    f2 t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(t) : "v"(a), "v"(w), "0"(t));
+    return t;
+}
+
+__device__ __forceinline__ void dft5(f2 v0, f2 v1, f2 v2, f2 v3, f2 v4, f2 &y0, f2 &y1, f2 &y2, f2 &y3, f2 &y4)
 {
     constexpr float C1 = FC_C1, C2 = FC_C2, S1 = FC_S1, S2 = FC_S2;
-    const float2 t1 = make_float2(v1.x + v4.x, v1.y + v4.y);
-    const float2 t2 = make_float2(v2.x + v3.x, v2.y + v3.y);
-    const float2 t3 = make_float2(v1.x - v4.x, v1.y - v4.y);
-    const float2 t4 = make_float2(v2.x - v3.x, v2.y - v3.y);
-    y0.x = (v0.x + t1.x) + t2.x;
-    y0.y = (v0.y + t1.y) + t2.y;
-    float2 m1, m2, n1, n2;
-    m1.x = __builtin_fmaf(C2, t2.x, __builtin_fmaf(C1, t1.x, v0.x));
-    m1.y = __builtin_fmaf(C2, t2.y, __builtin_fmaf(C1, t1.y, v0.y));
-    m2.x = __builtin_fmaf(C1, t2.x, __builtin_fmaf(C2, t1.x, v0.x));
-    m2.y = __builtin_fmaf(C1, t2.y, __builtin_fmaf(C2, t1.y, v0.y));
-    n1.x = __builtin_fmaf(S2, t4.x, S1 * t3.x);
-    n1.y = __builtin_fmaf(S2, t4.y, S1 * t3.y);
-    n2.x = __builtin_fmaf(-S1, t4.x, S2 * t3.x);
-    n2.y = __builtin_fmaf(-S1, t4.y, S2 * t3.y);
-    y1 = make_float2(m1.x + n1.y, m1.y - n1.x);
-    y4 = make_float2(m1.x - n1.y, m1.y + n1.x);
-    y2 = make_float2(m2.x + n2.y, m2.y - n2.x);
-    y3 = make_float2(m2.x - n2.y, m2.y + n2.x);
+    const f2 t1 = v1 + v4, t2 = v2 + v3, t3 = v1 - v4, t4 = v2 - v3;
+    y0 = (v0 + t1) + t2;
+    const f2 m1 = pkfma(mk2(C2, C2), t2, pkfma(mk2(C1, C1), t1, v0));
+    const f2 m2 = pkfma(mk2(C1, C1), t2, pkfma(mk2(C2, C2), t1, v0));
+    const f2 n1 = pkfma(mk2(S2, S2), t4, mk2(S1, S1) * t3);
+    const f2 n2 = pkfma(mk2(-S1, -S1), t4, mk2(S2, S2) * t3);
+    // y1 = m1 - i n1, y4 = m1 + i n1, y2 = m2 - i n2, y3 = m2 + i n2
+    rot4(m1, n1, m2, n2, y1, y4, y2, y3);
 }
 
-__device__ __forceinline__ void dft25(float2 (&v)[25])
+__device__ __forceinline__ void dft25(f2 (&v)[25])
 {
     // stage 1 in place: A[n2][k1] lives in v[5*k1 + n2]
 #pragma unroll
     for (int n2 = 0; n2 < 5; ++n2) {
-        float2 a0, a1, a2, a3, a4;
+        f2 a0, a1, a2, a3, a4;
         dft5(v[n2], v[5 + n2], v[10 + n2], v[15 + n2], v[20 + n2], a0, a1, a2, a3, a4);
-        if (n2) {
-            a1 = cmul(a1, make_float2(kW25[n2 * 5 + 1][0], kW25[n2 * 5 + 1][1]));
-            a2 = cmul(a2, make_float2(kW25[n2 * 5 + 2][0], kW25[n2 * 5 + 2][1]));
-            a3 = cmul(a3, make_float2(kW25[n2 * 5 + 3][0], kW25[n2 * 5 + 3][1]));
-            a4 = cmul(a4, make_float2(kW25[n2 * 5 + 4][0], kW25[n2 * 5 + 4][1]));
-        }
+        if (n2)
+            cmul4_k(a1, a2, a3, a4, mk2(kW25[n2 * 5 + 1][0], kW25[n2 * 5 + 1][1]),
+                    mk2(kW25[n2 * 5 + 2][0], kW25[n2 * 5 + 2][1]), mk2(kW25[n2 * 5 + 3][0], kW25[n2 * 5 + 3][1]),
+                    mk2(kW25[n2 * 5 + 4][0], kW25[n2 * 5 + 4][1]));
         v[n2] = a0;
         v[5 + n2] = a1;
         v[10 + n2] = a2;
@@ -69,7 +106,7 @@ __device__ __forceinline__ void dft25(float2 (&v)[25])
         v[20 + n2] = a4;
     }
     // stage 2: for each k1 a DFT5 over n2; output k1 + 5 k2
-    float2 o[25];
+    f2 o[25];
 #pragma unroll
     for (int k1 = 0; k1 < 5; ++k1)
         dft5(v[5 * k1], v[5 * k1 + 1], v[5 * k1 + 2], v[5 * k1 + 3], v[5 * k1 + 4], o[k1], o[k1 + 5], o[k1 + 10],
@@ -78,34 +115,39 @@ __device__ __forceinline__ void dft25(float2 (&v)[25])
     for (int i = 0; i < 25; ++i) v[i] = o[i];
 }
 
-__device__ __forceinline__ void dft10(float2 (&v)[10])
+__device__ __forceinline__ void dft10(f2 (&v)[10])
 {
-    float2 A0[5], A1[5];
+    f2 A0[5], A1[5];
     dft5(v[0], v[2], v[4], v[6], v[8], A0[0], A0[1], A0[2], A0[3], A0[4]);
     dft5(v[1], v[3], v[5], v[7], v[9], A1[0], A1[1], A1[2], A1[3], A1[4]);
-#pragma unroll
-    for (int k1 = 1; k1 < 5; ++k1) A1[k1] = cmul(A1[k1], make_float2(kW10[k1][0], kW10[k1][1]));
+    cmul4_k(A1[1], A1[2], A1[3], A1[4], mk2(kW10[1][0], kW10[1][1]), mk2(kW10[2][0], kW10[2][1]),
+            mk2(kW10[3][0], kW10[3][1]), mk2(kW10[4][0], kW10[4][1]));
 #pragma unroll
     for (int k1 = 0; k1 < 5; ++k1) {
-        v[k1] = make_float2(A0[k1].x + A1[k1].x, A0[k1].y + A1[k1].y);
-        v[k1 + 5] = make_float2(A0[k1].x - A1[k1].x, A0[k1].y - A1[k1].y);
+        v[k1] = A0[k1] + A1[k1];
+        v[k1 + 5] = A0[k1] - A1[k1];
     }
 }
 
 // Complex FFT of length 6250 of the sequence whose pass-1 butterfly inputs are already in
 // v (thread tid < 250 holds z[tid + 250 r], r = 0..24).  Result Z[0..6249] in buf (natural order).
-__device__ __forceinline__ void fft6250(float2 (&v)[25], float2 *buf, const float2 *__restrict__ tw2,
-                                        const float2 *__restrict__ tw3, int tid)
+__device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restrict__ tw2,
+                                        const f2 *__restrict__ tw3, int tid)
 {
     // Twiddles of the next pass are requested BEFORE the barriers that precede their use, so
     // that their L2 latency hides under this pass's arithmetic and LDS traffic.
     const int k = tid % 25;
-    float2 t2[24];
-    float2 t3[3][9];
+    f2 t2[24];
+    f2 t3[3][9];
+    // twiddle tables through buffer descriptors: the per-r row offset goes in the scalar offset, so
+    // the loads need no 64-bit vector address arithmetic
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)tw2, 0, 625 * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc((void *)tw3, 0, M_HALF * 8, 0x00020000);
     auto load_t2 = [&]() {
         if (tid < 250) {
 #pragma unroll
-            for (int r = 1; r < 25; ++r) t2[r - 1] = tw2[r * 25 + k];
+            for (int r = 1; r < 25; ++r)
+                t2[r - 1] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs2, k * 8, r * 200, 0));
         }
     };
     auto load_t3 = [&]() {
@@ -114,7 +156,9 @@ __device__ __forceinline__ void fft6250(float2 (&v)[25], float2 *buf, const floa
             const int j = tid + 256 * i;
             if (j < 625) {
 #pragma unroll
-                for (int r = 1; r < 10; ++r) t3[i][r - 1] = tw3[r * 625 + j];
+                for (int r = 1; r < 10; ++r)
+                    t3[i][r - 1] =
+                        __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs3, j * 8, r * 5000, 0));
             }
         }
     };
@@ -142,7 +186,8 @@ __device__ __forceinline__ void fft6250(float2 (&v)[25], float2 *buf, const floa
 #endif
     if (tid < 250) {
 #pragma unroll
-        for (int r = 1; r < 25; ++r) v[r] = cmul(v[r], t2[r - 1]);
+        for (int r = 1; r < 25; r += 4)
+            cmul4(v[r], v[r + 1], v[r + 2], v[r + 3], t2[r - 1], t2[r], t2[r + 1], t2[r + 2]);
         dft25(v);
         const int j0 = (tid / 25) * 625 + k;
 #pragma unroll
@@ -150,7 +195,7 @@ __device__ __forceinline__ void fft6250(float2 (&v)[25], float2 *buf, const floa
     }
     __syncthreads();
     // pass 3: R = 10, Ns = 625; butterflies j = tid, tid + 256, tid + 512
-    float2 u[3][10];
+    f2 u[3][10];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int j = tid + 256 * i;
@@ -167,8 +212,9 @@ __device__ __forceinline__ void fft6250(float2 (&v)[25], float2 *buf, const floa
     for (int i = 0; i < 3; ++i) {
         const int j = tid + 256 * i;
         if (j < 625) {
-#pragma unroll
-            for (int r = 1; r < 10; ++r) u[i][r] = cmul(u[i][r], t3[i][r - 1]);
+            cmul4(u[i][1], u[i][2], u[i][3], u[i][4], t3[i][0], t3[i][1], t3[i][2], t3[i][3]);
+            cmul4(u[i][5], u[i][6], u[i][7], u[i][8], t3[i][4], t3[i][5], t3[i][6], t3[i][7]);
+            u[i][9] = cmul(u[i][9], t3[i][8]);
             dft10(u[i]);
 #pragma unroll
             for (int r = 0; r < 10; ++r) buf[j + 625 * r] = u[i][r];
@@ -178,16 +224,34 @@ __device__ __forceinline__ void fft6250(float2 (&v)[25], float2 *buf, const floa
 }
 
 // real-input split: X[k] = 0.5 (E + T[k] O), E = Z[k] + conj Z[M-k], O = Z[k] - conj Z[M-k]
-__device__ __forceinline__ float2 rsplit(const float2 *buf, const float2 *__restrict__ post, int k)
+__device__ __forceinline__ f2 rsplit(const f2 *buf, const f2 *__restrict__ post, int k)
 {
-    const float2 a = buf[k == M_HALF ? 0 : k];
-    float2 b = buf[k == 0 ? 0 : M_HALF - k];
+    const f2 a = buf[k == M_HALF ? 0 : k];
+    f2 b = buf[k == 0 ? 0 : M_HALF - k];
     b.y = -b.y;
-    const float2 E = make_float2(a.x + b.x, a.y + b.y);
-    const float2 O = make_float2(a.x - b.x, a.y - b.y);
-    const float2 P = cmul(O, post[k]);
-    return make_float2(0.5f * (E.x + P.x), 0.5f * (E.y + P.y));
+    const f2 E = a + b, O = a - b;
+    const f2 P = cmul(O, post[k]);
+    return mk2(0.5f, 0.5f) * (E + P);
 }
 
 __device__ __forceinline__ float cvt_sample_c(unsigned u) { return u == 0 ? 0.0f : (float)u / 128 - 1; }
+
+// convertarray (src/pb_kernels.cu:23-33) on packed codes.  u / 128 and the subtraction of 1 are both
+// exact in binary32, so fma(u, 1/128, -1) is the same number; code 0 ("no sample" -> 0.0) is first
+// rewritten as code 128, whose value is 0.0.
+__device__ __forceinline__ unsigned fix_zero_codes(unsigned w)
+{
+    const unsigned t = ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w;   // bit 7 of a byte set <=> byte != 0
+    return w | (~t & 0x80808080u);
+}
+__device__ __forceinline__ uint4 fix_zero_codes(uint4 q)
+{
+    return make_uint4(fix_zero_codes(q.x), fix_zero_codes(q.y), fix_zero_codes(q.z), fix_zero_codes(q.w));
+}
+// two fixed codes (low byte = even sample = re, next byte = odd sample = im) -> (re, im)
+__device__ __forceinline__ f2 cvt_pair_c(unsigned w)
+{
+    const f2 u = mk2((float)(w & 0xffu), (float)((w >> 8) & 0xffu));
+    return pkfma(u, mk2(0.0078125f, 0.0078125f), mk2(-1.0f, -1.0f));
+}
 

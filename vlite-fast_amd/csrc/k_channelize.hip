@@ -45,7 +45,7 @@ struct ChanArgs {
 // One transform of one (row, pol): ROLE 0 = raw spectrum (also fills the excised plane when the row
 // has no flagged block), ROLE 1 = excised spectrum (flagged blocks zeroed).
 template <int ROLE>
-__device__ __forceinline__ void channelize_pass(const ChanArgs &a, float2 *buf, int tid, int seg, int row, int pol,
+__device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int tid, int seg, int row, int pol,
                                                 int ant, unsigned mask, float wrow, size_t prow)
 {
 
@@ -64,26 +64,28 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, float2 *buf, 
         const bool has3 = tid + 768 < nch;
         uint4 t3 = make_uint4(0u, 0u, 0u, 0u);
         if (has3) t3 = src16[tid + 768];
+        // a dropped-frame byte (0) means "no sample" = 0.0 = code 128 (convertarray :23-33): patch the
+        // codes here, four per instruction, so that the conversion below is one fma per sample pair
         uint4 *stage = (uint4 *)buf;
-        stage[tid] = t0;
-        stage[tid + 256] = t1;
-        stage[tid + 512] = t2;
-        if (has3) stage[tid + 768] = t3;
+        stage[tid] = fix_zero_codes(t0);
+        stage[tid + 256] = fix_zero_codes(t1);
+        stage[tid + 512] = fix_zero_codes(t2);
+        if (has3) stage[tid + 768] = fix_zero_codes(t3);
     }
     __syncthreads();
-    float2 v[25];
+    f2 v[25];
     if (tid < 250) {
         const unsigned zmask = ROLE == 1 ? mask : 0u;
         const uint16_t *sb = (const uint16_t *)((const uint8_t *)buf + o);
 #pragma unroll
         for (int r = 0; r < 25; ++r) {
-            const unsigned w = sb[tid + 250 * r];
-            v[r] = ((zmask >> r) & 1u) ? make_float2(0.f, 0.f)
-                                       : make_float2(cvt_sample_c(w & 0xff), cvt_sample_c(w >> 8));
+            unsigned w = sb[tid + 250 * r];
+            if ((zmask >> r) & 1u) w = 0x8080u;   // flagged block -> zeros (apply_kurtosis :243-295)
+            v[r] = cvt_pair_c(w);
         }
     }
     __syncthreads();   // all samples are in registers before pass 1 overwrites buf
-    fft6250(v, buf, a.tw2, a.tw3, tid);
+    fft6250(v, buf, (const f2 *)a.tw2, (const f2 *)a.tw3, tid);
 
     // FRB injection window of this row, per channel (inject_frb :361-380)
     const bool inject = a.frb.delays != nullptr && a.inject_now > 0;
@@ -95,31 +97,25 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, float2 *buf, 
     for (int c4 = tid * 4; c4 < PB_NCHANOUT; c4 += 1024) {
         const float4 t01 = *(const float4 *)(a.postc + c4);
         const float4 t23 = *(const float4 *)(a.postc + c4 + 2);
-        const float2 tw[4] = {make_float2(t01.x, t01.y), make_float2(t01.z, t01.w), make_float2(t23.x, t23.y),
-                              make_float2(t23.z, t23.w)};
+        const f2 tw[4] = {mk2(t01.x, t01.y), mk2(t01.z, t01.w), mk2(t23.x, t23.y), mk2(t23.z, t23.w)};
         float pw[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = PB_CHANMIN + c4 + q;
-            const float2 za = buf[k == M_HALF ? 0 : k];
-            float2 zb = buf[M_HALF - k];
+            const f2 za = buf[k == M_HALF ? 0 : k];
+            f2 zb = buf[M_HALF - k];
             zb.y = -zb.y;
-            const float2 E = make_float2(za.x + zb.x, za.y + zb.y);
-            const float2 O = make_float2(za.x - zb.x, za.y - zb.y);
-            const float2 Pq = cmul(O, tw[q]);
-            float2 X = make_float2(0.5f * (E.x + Pq.x), 0.5f * (E.y + Pq.y));
+            const f2 E = za + zb, O = za - zb;
+            const f2 Pq = cmul(O, tw[q]);
+            f2 X = mk2(0.5f, 0.5f) * (E + Pq);
             if (inject) {
                 const float d = a.frb.delays[k];
                 const int lo = (int)(d + 0.5) - since;
                 const int hi = (int)(d + a.frb.width + 0.5) - since;
-                if (row >= lo && row <= hi) {
-                    X.x *= a.frb.amp;
-                    X.y *= a.frb.amp;
-                }
+                if (row >= lo && row <= hi) X = X * mk2(a.frb.amp, a.frb.amp);
             }
-            const float xx = X.x * X.x;
-            const float yy = X.y * X.y;
-            pw[q] = xx + yy;
+            const f2 sq = X * X;
+            pw[q] = sq.x + sq.y;
         }
         // the excised plane carries pow / w (detect_and_normalize3 :452,:481), so that the
         // serial bandpass recurrence downstream has no division in it
@@ -135,7 +131,7 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, float2 *buf, 
 // bound by VALU issue, so running them side by side only stretches each (profiles/r01 notes).
 __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
 {
-    __shared__ float2 buf[M_HALF];
+    __shared__ f2 buf[M_HALF];
     int tid = threadIdx.x;
     const int grow = blockIdx.x;  // seg * R + row
     const int pol = blockIdx.y, ant = blockIdx.z;
@@ -242,17 +238,17 @@ __global__ __launch_bounds__(256) void k_channelize_f32(const float *__restrict_
                                                         const float *__restrict__ fir, float2 *__restrict__ out,
                                                         const float2 *tw2, const float2 *tw3, const float2 *post)
 {
-    __shared__ float2 buf[M_HALF];
+    __shared__ f2 buf[M_HALF];
     const int tid = threadIdx.x;
     const size_t row = blockIdx.x;
     const float *xr = x + row * PB_NFFT;
-    float2 v[25];
+    f2 v[25];
     if (tid < 250) {
 #pragma unroll
         for (int r = 0; r < 25; ++r) {
             const int n = 2 * (tid + 250 * r);
             if (taps == 1) {
-                v[r] = *(const float2 *)(xr + n);
+                v[r] = *(const f2 *)(xr + n);
             } else {
                 float2 acc = make_float2(0.f, 0.f);
                 for (int j = 0; j < 4; ++j) {
@@ -262,12 +258,15 @@ __global__ __launch_bounds__(256) void k_channelize_f32(const float *__restrict_
                     acc.x = j ? acc.x + px : px;
                     acc.y = j ? acc.y + py : py;
                 }
-                v[r] = acc;
+                v[r] = mk2(acc.x, acc.y);
             }
         }
     }
-    fft6250(v, buf, tw2, tw3, tid);
-    for (int k = tid; k < PB_NCHAN; k += 256) out[row * PB_NCHAN + k] = rsplit(buf, post, k);
+    fft6250(v, buf, (const f2 *)tw2, (const f2 *)tw3, tid);
+    for (int k = tid; k < PB_NCHAN; k += 256) {
+        const f2 X = rsplit(buf, (const f2 *)post, k);
+        out[row * PB_NCHAN + k] = make_float2(X.x, X.y);
+    }
 }
 
 hipError_t launch_channelize_f32(pb_handle *h, const float *d_x, int nrows, int taps, float2 *d_out)

@@ -49,7 +49,7 @@ __device__ __forceinline__ unsigned row_mask(const PfbArgs &a, int ant, int rr)
 __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4 * PFB_ROW_LDS];   // 50 112 B, reused as the FFT buffer
-    float2 *buf = (float2 *)lds;
+    f2 *buf = (f2 *)lds;
     const int tid = threadIdx.x;
     const int grow = blockIdx.x;
     const int pol = blockIdx.y & 1, ant = blockIdx.z;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
     }
     __syncthreads();
 
-    float2 v[25];
+    f2 v[25];
     if (tid < 250) {
         const bool kur = role == 1;
         const uint16_t *s0 = (const uint16_t *)(lds + 0 * PFB_ROW_LDS + off[0]);
@@ -133,11 +133,11 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
             const float p3x = t3.x * cvt_sample_c(w3 & 0xff), p3y = t3.y * cvt_sample_c(w3 >> 8);
             ax = ax + p3x;
             ay = ay + p3y;
-            v[r] = make_float2(ax, ay);
+            v[r] = mk2(ax, ay);
         }
     }
     __syncthreads();
-    fft6250(v, buf, a.tw2, a.tw3, tid);
+    fft6250(v, buf, (const f2 *)a.tw2, (const f2 *)a.tw3, tid);
 
     const bool inject = a.frb.delays != nullptr && a.inject_now > 0;
     const int since = inject ? (a.inject_now - 1 + seg) * a.R : 0;
@@ -147,31 +147,25 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
     for (int c4 = tid * 4; c4 < PB_NCHANOUT; c4 += 1024) {
         const float4 t01 = *(const float4 *)(a.postc + c4);
         const float4 t23 = *(const float4 *)(a.postc + c4 + 2);
-        const float2 tw[4] = {make_float2(t01.x, t01.y), make_float2(t01.z, t01.w), make_float2(t23.x, t23.y),
-                              make_float2(t23.z, t23.w)};
+        const f2 tw[4] = {mk2(t01.x, t01.y), mk2(t01.z, t01.w), mk2(t23.x, t23.y), mk2(t23.z, t23.w)};
         float pw[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = PB_CHANMIN + c4 + q;
-            const float2 za = buf[k == M_HALF ? 0 : k];
-            float2 zb = buf[M_HALF - k];
+            const f2 za = buf[k == M_HALF ? 0 : k];
+            f2 zb = buf[M_HALF - k];
             zb.y = -zb.y;
-            const float2 E = make_float2(za.x + zb.x, za.y + zb.y);
-            const float2 O = make_float2(za.x - zb.x, za.y - zb.y);
-            const float2 Pq = cmul(O, tw[q]);
-            float2 X = make_float2(0.5f * (E.x + Pq.x), 0.5f * (E.y + Pq.y));
+            const f2 E = za + zb, O = za - zb;
+            const f2 Pq = cmul(O, tw[q]);
+            f2 X = mk2(0.5f, 0.5f) * (E + Pq);
             if (inject) {
                 const float d = a.frb.delays[k];
                 const int lo = (int)(d + 0.5) - since;
                 const int hi = (int)(d + a.frb.width + 0.5) - since;
-                if (row >= lo && row <= hi) {
-                    X.x *= a.frb.amp;
-                    X.y *= a.frb.amp;
-                }
+                if (row >= lo && row <= hi) X = X * mk2(a.frb.amp, a.frb.amp);
             }
-            const float xx = X.x * X.x;
-            const float yy = X.y * X.y;
-            pw[q] = xx + yy;
+            const f2 sq = X * X;
+            pw[q] = sq.x + sq.y;
         }
         if (role == 0) *(float4 *)(P0 + c4) = make_float4(pw[0], pw[1], pw[2], pw[3]);
         if (role == 1 || also_kur)
