@@ -6,6 +6,7 @@
 #include "pb_internal.h"
 
 #define M_HALF 6250
+
 #ifndef FFT_PREFETCH
 #define FFT_PREFETCH 1   // bit 0: pass-2 twiddles, bit 1: pass-3 twiddles requested one barrier early
 #endif
@@ -40,6 +41,15 @@ __device__ __forceinline__ void rot4(f2 m1, f2 n1, f2 m2, f2 n2, f2 &y1, f2 &y4,
         "v_pk_add_f32 %3, %6, %7 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"
         : "=&v"(y1), "=&v"(y4), "=&v"(y2), "=&v"(y3)
         : "v"(m1), "v"(n1), "v"(m2), "v"(n2));
+}
+
+// E = a + conj(b), O = a - conj(b)
+__device__ __forceinline__ void addsub_conj(f2 a, f2 b, f2 &E, f2 &O)
+{
+    asm("v_pk_add_f32 %0, %2, %3 neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %2, %3 neg_lo:[0,1]"
+        : "=&v"(E), "=&v"(O)
+        : "v"(a), "v"(b));
 }
 
 // a *= w, complex: (a.x w.x - a.y w.y, a.x w.y + a.y w.x) evaluated as
@@ -185,16 +195,17 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
     load_t3();
 #endif
     if (tid < 250) {
+        const int j0 = (tid / 25) * 625 + k;
 #pragma unroll
         for (int r = 1; r < 25; r += 4)
             cmul4(v[r], v[r + 1], v[r + 2], v[r + 3], t2[r - 1], t2[r], t2[r + 1], t2[r + 2]);
         dft25(v);
-        const int j0 = (tid / 25) * 625 + k;
 #pragma unroll
         for (int r = 0; r < 25; ++r) buf[j0 + 25 * r] = v[r];
     }
     __syncthreads();
-    // pass 3: R = 10, Ns = 625; butterflies j = tid, tid + 256, tid + 512
+    // pass 3: R = 10, Ns = 625; butterflies j = tid, tid + 256, tid + 512, each in place on
+    // buf[j + 625 r] (no barrier between its loads and its stores)
     f2 u[3][10];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -204,7 +215,6 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
             for (int r = 0; r < 10; ++r) u[i][r] = buf[j + 625 * r];
         }
     }
-    __syncthreads();
 #if !(FFT_PREFETCH & 2)
     load_t3();
 #endif

@@ -93,7 +93,9 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
     const bool also_kur = a.rfi_mode == 2 && ROLE == 0 && mask == 0;
     float *P0 = (ROLE == 1 ? a.Pkur : a.Praw) + prow;
     float *P1 = a.Pkur + prow;
-    // four consecutive channels per thread: 16-byte twiddle loads and 16-byte power stores
+    // four consecutive channels per thread: 16-byte twiddle loads and 16-byte power stores (one
+    // channel per lane would spare the 8-way LDS bank conflicts of these reads, but its 4-byte stores
+    // measured 9 % slower overall)
     for (int c4 = tid * 4; c4 < PB_NCHANOUT; c4 += 1024) {
         const float4 t01 = *(const float4 *)(a.postc + c4);
         const float4 t23 = *(const float4 *)(a.postc + c4 + 2);
@@ -103,9 +105,9 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
         for (int q = 0; q < 4; ++q) {
             const int k = PB_CHANMIN + c4 + q;
             const f2 za = buf[k == M_HALF ? 0 : k];
-            f2 zb = buf[M_HALF - k];
-            zb.y = -zb.y;
-            const f2 E = za + zb, O = za - zb;
+            const f2 zb = buf[M_HALF - k];
+            f2 E, O;
+            addsub_conj(za, zb, E, O);
             const f2 Pq = cmul(O, tw[q]);
             f2 X = mk2(0.5f, 0.5f) * (E + Pq);
             if (inject) {
@@ -126,9 +128,12 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
     }
 }
 
-// Three workgroups per CU (LDS 3 x 50 000 B, <= 168 VGPRs).  Measured: capping residency at two
-// to let a detect workgroup of the previous batch co-reside does not pay -- both kernels are
-// bound by VALU issue, so running them side by side only stretches each (profiles/r01 notes).
+// Three workgroups per CU (LDS 3 x 50 000 B, <= 168 VGPRs).  Measured (profiles/r01 notes):
+//  * capping residency at two to let a detect workgroup of the previous batch co-reside does not
+//    pay -- both kernels are bound by VALU issue, so side by side they only stretch each other;
+//  * persistent workgroups that prefetch the next row into registers are 12 % SLOWER than one
+//    workgroup per (row, pol): the hardware dispatcher's staggered starts overlap the workgroups'
+//    load, FFT and store phases better than a lock-step loop does.
 __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
 {
     __shared__ f2 buf[M_HALF];
@@ -150,8 +155,6 @@ __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
     // no flagged block), role 1 = excised spectrum (only when some block is flagged: 13 % of rows on
     // clean noise).  One workgroup per (row, pol) does both, instead of launching a second grid of
     // workgroups of which 87 % would exit at once.
-    const int role_first = a.rfi_mode == 1 ? 1 : 0;
-    const int role_last = a.rfi_mode == 0 ? 0 : ((a.rfi_mode == 2 && mask == 0) ? 0 : 1);
 
     // row weight exactly as apply_kurtosis accumulates it: one 500/12500 per unflagged block
     float wrow = 0.f;
