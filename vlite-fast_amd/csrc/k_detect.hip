@@ -247,6 +247,32 @@ hipError_t launch_inject_c64(pb_handle *h, int nseg, int inject_now)
     return hipGetLastError();
 }
 
+// Filterbank bytes to the pinned host mirror.  A kernel storing straight into the mapped host buffer
+// instead of hipMemcpyAsync: on this stack an asynchronous D2H copy blocks the calling host thread for
+// 5-7 ms every twenty-odd calls (measured with PB_TRACE-style timers around each runtime call), which
+// is six batches' worth of GPU time.  10 MB per second of data per antenna is nothing for PCIe.
+__global__ __launch_bounds__(256) void k_copy_out(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+hipError_t launch_copy_out(uint8_t *host_pinned, const uint8_t *dev, size_t nbytes, hipStream_t st)
+{
+    if (nbytes == 0) return hipSuccess;
+    if ((nbytes & 15) || ((uintptr_t)host_pinned & 15) || ((uintptr_t)dev & 15))
+        return hipMemcpyAsync(host_pinned, dev, nbytes, hipMemcpyDeviceToHost, st);
+    void *dptr = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&dptr, host_pinned, 0);
+    if (e != hipSuccess) return e;
+    const size_t n16 = nbytes >> 4;
+    // 8 workgroups saturate PCIe (10 MB in ~0.2 ms); more only hold store queues of more CUs full,
+    // which slows the channeliser running beside them (32: +10 % on the step).  PB_COPY_WGS overrides.
+    static const int maxb = getenv("PB_COPY_WGS") ? atoi(getenv("PB_COPY_WGS")) : 8;
+    const unsigned nb = (unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)maxb);
+    k_copy_out<<<nb, 256, 0, st>>>((uint4 *)dptr, (const uint4 *)dev, n16);
+    return hipGetLastError();
+}
+
 hipError_t launch_detect(pb_handle *h, int nseg, int)
 {
     if (h->cfg.fft_backend != PB_FFT_HIPFFT) return launch_detect_pow(h, nseg);

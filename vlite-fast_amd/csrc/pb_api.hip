@@ -613,6 +613,25 @@ static hipEvent_t take_event(pb_handle *h)
     return e;
 }
 
+// Read back the oldest event pairs that have completed, without waiting for anything: keeps the
+// pool small, so that a long profiled run creates no events (hipEventCreate costs tens of us).
+static void retire_done(pb_handle *h)
+{
+    size_t n = 0;
+    while (n < h->pending.size() && hipEventQuery(h->pending[n].b) == hipSuccess) {
+        const auto &p = h->pending[n];
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            h->timers.ms[p.stage] += ms;
+            h->timers.launches[p.stage] += 1;
+        }
+        h->ev_pool.push_back(p.a);
+        h->ev_pool.push_back(p.b);
+        ++n;
+    }
+    if (n) h->pending.erase(h->pending.begin(), h->pending.begin() + n);
+}
+
 struct StageTimer {
     pb_handle *h;
     int stage;
@@ -620,6 +639,7 @@ struct StageTimer {
     StageTimer(pb_handle *h_, int s) : h(h_), stage(s), a(nullptr), b(nullptr)
     {
         if (h->profile) {
+            if (h->ev_pool.size() < 2) retire_done(h);
             a = take_event(h);
             b = take_event(h);
             (void)hipEventRecord(a, h->stream);
@@ -754,8 +774,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
             for (int st = 0; st < 2 && e2 == hipSuccess; ++st) {
                 if (st == 0 ? h->cfg.rfi_mode == 1 : h->cfg.rfi_mode == 0) continue;
                 const size_t o = ((size_t)a * 2 + st) * h->S * h->trim;
-                e2 = hipMemcpyAsync(h->h_codes + o, h->d_codes + o, (size_t)nseg * h->trim,
-                                    hipMemcpyDeviceToHost, h->s_det);
+                e2 = launch_copy_out(h->h_codes + o, h->d_codes + o, (size_t)nseg * h->trim, h->s_det);
             }
         if (e2 == hipSuccess) e2 = hipEventRecord(h->ev_det, h->s_det);
         if (e2 == hipSuccess) e2 = hipEventRecord(h->ev_alldone, h->s_det);
@@ -777,8 +796,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         for (int st = 0; st < 2 && e == hipSuccess; ++st) {
             if (st == 0 ? h->cfg.rfi_mode == 1 : h->cfg.rfi_mode == 0) continue;
             const size_t o = ((size_t)a * 2 + st) * h->S * h->trim;
-            e = hipMemcpyAsync(h->h_codes + o, h->d_codes + o, (size_t)nseg * h->trim, hipMemcpyDeviceToHost,
-                               h->s_det);
+            e = launch_copy_out(h->h_codes + o, h->d_codes + o, (size_t)nseg * h->trim, h->s_det);
         }
     if (e == hipSuccess) e = hipEventRecord(h->ev_det, h->s_det);
     HIPCHK(h, e);
@@ -899,8 +917,8 @@ extern "C" int pb_coadd_finish(pb_handle *h, int nseg, const float *d_sum, int n
     HIPCHK(h, launch_coadd_digitise(h, nseg, d_sum, scale, h->d_coadd_codes + slot * nb));
     HIPCHK(h, hipEventRecord(h->ev_chan, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->s_det, h->ev_chan, 0));
-    HIPCHK(h, hipMemcpyAsync(h->h_coadd_codes + slot * nb, h->d_coadd_codes + slot * nb, (size_t)nseg * h->trim,
-                             hipMemcpyDeviceToHost, h->s_det));
+    HIPCHK(h, launch_copy_out(h->h_coadd_codes + slot * nb, h->d_coadd_codes + slot * nb, (size_t)nseg * h->trim,
+                              h->s_det));
     HIPCHK(h, hipEventRecord(h->ev_coadd[slot], h->s_det));
     if (codes_host) {
         HIPCHK(h, hipEventSynchronize(h->ev_coadd[slot]));
@@ -925,6 +943,15 @@ extern "C" int pb_profile(pb_handle *h, int enable)
 {
     if (!h) return PB_EINVAL;
     h->profile = enable != 0;
+    if (h->profile) {
+        // enough events for a few batches in flight; later ones are recycled by retire_done
+        (void)hipSetDevice(h->cfg.device);
+        while (h->ev_pool.size() < 64) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            h->ev_pool.push_back(e);
+        }
+    }
     return PB_OK;
 }
 

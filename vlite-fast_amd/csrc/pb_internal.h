@@ -111,6 +111,8 @@ hipError_t launch_deframe(pb_handle *h, int ant, int seg0, size_t nframes_per_th
 hipError_t launch_inject_c64(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_detect(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_detect_pow(pb_handle *h, int nseg);
+// device -> pinned host copy done by a kernel (see k_detect.hip: hipMemcpyAsync blocks the host now and then)
+hipError_t launch_copy_out(uint8_t *host_pinned, const uint8_t *dev, size_t nbytes, hipStream_t st);
 hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_channelize_f32(pb_handle *h, const float *d_x, int nrows, int taps, float2 *d_out);
