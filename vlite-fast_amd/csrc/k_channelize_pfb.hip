@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
         const uint4 *src16 = (const uint4 *)(base + (rbyte - o));
         const int nch = (int)((o + PB_NFFT + 15) >> 4);
         uint4 *dst = (uint4 *)(lds + j * PFB_ROW_LDS);
-        for (int i = tid; i < nch; i += 256) dst[i] = src16[i];
+        // code 0 ("no sample") becomes code 128 = 0.0 here, four bytes per instruction (fft_lds.h)
+        for (int i = tid; i < nch; i += 256) dst[i] = fix_zero_codes(src16[i]);
     }
     __syncthreads();
 
@@ -110,30 +111,35 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
         const uint16_t *s1 = (const uint16_t *)(lds + 1 * PFB_ROW_LDS + off[1]);
         const uint16_t *s2 = (const uint16_t *)(lds + 2 * PFB_ROW_LDS + off[2]);
         const uint16_t *s3 = (const uint16_t *)(lds + 3 * PFB_ROW_LDS + off[3]);
+        // window coefficients of samples (2n, 2n+1), n = tid + 250 r, tap j: through a buffer descriptor
+        // with the lane part (8 tid) in the vector offset and (j, r) in the scalar offset
+        const __amdgpu_buffer_rsrc_t rsF =
+            __builtin_amdgcn_make_buffer_rsrc((void *)a.fir, 0, 4 * PB_NFFT * 4, 0x00020000);
+        auto coef = [&](int j, int r) __attribute__((always_inline)) {
+            return __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rsF, tid * 8, (j * PB_NFFT + 500 * r) * 4, 0));
+        };
+        const unsigned m0 = kur ? mask[0] : 0u, m1 = kur ? mask[1] : 0u, m2 = kur ? mask[2] : 0u,
+                       m3 = kur ? mask[3] : 0u;
 #pragma unroll
         for (int r = 0; r < 25; ++r) {
             const int n = tid + 250 * r;
-            const unsigned w0 = (kur && ((mask[0] >> r) & 1u)) ? 0u : s0[n];
-            const unsigned w1 = (kur && ((mask[1] >> r) & 1u)) ? 0u : s1[n];
-            const unsigned w2 = (kur && ((mask[2] >> r) & 1u)) ? 0u : s2[n];
-            const unsigned w3 = (kur && ((mask[3] >> r) & 1u)) ? 0u : s3[n];
-            const float2 t0 = *(const float2 *)(a.fir + 0 * PB_NFFT + 2 * n);
-            const float2 t1 = *(const float2 *)(a.fir + 1 * PB_NFFT + 2 * n);
-            const float2 t2 = *(const float2 *)(a.fir + 2 * PB_NFFT + 2 * n);
-            const float2 t3 = *(const float2 *)(a.fir + 3 * PB_NFFT + 2 * n);
-            // sum_j taps[j] * x_j, products then left-to-right adds (the order of k_channelize_f32)
-            float ax = t0.x * cvt_sample_c(w0 & 0xff);
-            float ay = t0.y * cvt_sample_c(w0 >> 8);
-            const float p1x = t1.x * cvt_sample_c(w1 & 0xff), p1y = t1.y * cvt_sample_c(w1 >> 8);
-            ax = ax + p1x;
-            ay = ay + p1y;
-            const float p2x = t2.x * cvt_sample_c(w2 & 0xff), p2y = t2.y * cvt_sample_c(w2 >> 8);
-            ax = ax + p2x;
-            ay = ay + p2y;
-            const float p3x = t3.x * cvt_sample_c(w3 & 0xff), p3y = t3.y * cvt_sample_c(w3 >> 8);
-            ax = ax + p3x;
-            ay = ay + p3y;
-            v[r] = mk2(ax, ay);
+            // a flagged block contributes zeros = code 128 (apply_kurtosis :243-295)
+            // (bit arithmetic, not a select: the compiler turns a select on this wave-uniform condition
+            // into a branch around each LDS read)
+            auto pick = [&](unsigned m, unsigned raw) __attribute__((always_inline)) {
+                const unsigned z = 0u - ((m >> r) & 1u);          // all ones when block r is flagged
+                return (raw & ~z) | (0x8080u & z);
+            };
+            const unsigned w0 = pick(m0, s0[n]), w1 = pick(m1, s1[n]), w2 = pick(m2, s2[n]), w3 = pick(m3, s3[n]);
+            // sum_j taps[j] * x_j, products then left-to-right adds (the order of k_channelize_f32),
+            // re and im side by side in packed instructions
+            f2 acc = coef(0, r) * cvt_pair_c(w0);
+            acc = acc + coef(1, r) * cvt_pair_c(w1);
+            acc = acc + coef(2, r) * cvt_pair_c(w2);
+            acc = acc + coef(3, r) * cvt_pair_c(w3);
+            v[r] = acc;
+            // five blocks at a time: letting the scheduler hoist all 100 coefficient loads spills
+            if (r % 5 == 4) __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();
