@@ -125,6 +125,44 @@ def test_lds_backend_bit_exact(oracle, data, rfi_mode, npol, nbit):
         assert _same_bits(gk, bp_raw.reshape(2, NCHAN)[:, 2155:])
 
 
+@pytest.mark.parametrize("case", ["dropped_segment", "constant_128", "saturated", "one_pol_dead"])
+def test_lds_backend_degenerate_inputs(oracle, case):
+    """Inputs the live system does meet: a whole segment of dropped frames (zeros -> kurtosis NaN,
+    zero power, bandpass initialised from a zero mean), a dead digitiser (constant mid-scale or rail),
+    one polarisation missing.  Codes, fp32 planes (NaN bit patterns included) and bandpass state must
+    still equal the oracle's."""
+    lp = libpb()
+    d = make_input(11, R, NSEG, rfi=False, dropped=False)
+    if case == "dropped_segment":
+        d[0] = 0
+        d[2, 0, :] = 0
+    elif case == "constant_128":
+        d[1] = 128
+    elif case == "saturated":
+        d[0, 1] = 255
+        d[1, 0, 12500 * 3:12500 * 9] = 255
+    else:
+        d[:, 1] = 0
+    g = _run_gpu(lp, d, lp.FFT_LDS, rfi_mode=2, npol=1, nbit=8)
+    res, bp_raw, bp_kur = oracle_run(oracle, d, R, rfi_mode=2, npol=1, nbit=8)
+    for name in ("raw", "kur"):
+        refa = np.concatenate([compact_ave(getattr(r, "ave_" + name), R, 1) for r in res])
+        ga = g["ave_" + name]
+        # NaNs may differ in payload/sign between a CPU and a GPU divide; they must sit in the same places
+        assert np.array_equal(np.isnan(ga), np.isnan(refa)), "%s: NaN positions differ" % name
+        ok = ~np.isnan(refa)
+        assert _same_bits(ga[ok], refa[ok]), "%s fp32 plane differs" % name
+        # ... and the quantiser sends a NaN to the same code on both sides (0 for 8 bits)
+        ref = np.concatenate([getattr(r, "codes_" + name) for r in res])
+        assert np.array_equal(g[name], ref), "%s codes differ from the oracle" % name
+    gr, gk = g["bp"]
+    for got, ref in ((gr, bp_raw), (gk, bp_kur)):
+        ref = ref.reshape(2, NCHAN)[:, 2155:]
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        m = ~np.isnan(ref)
+        assert _same_bits(got[m], ref[m])
+
+
 def test_channelizer_fft_matches_oracle_fft_bitwise(oracle):
     import synth
     lp = libpb()
