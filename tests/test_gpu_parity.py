@@ -191,21 +191,25 @@ def test_pfb_taps4_matches_reference_polyphase_filterbank(golden, oracle):
 # ---------------------------------------------------------------------------
 # antenna batching on one GPU + incoherent coadd
 
-def test_antenna_batch_and_coadd(oracle):
+@pytest.mark.parametrize("nsets", [1, 2])
+def test_antenna_batch_and_coadd(oracle, nsets):
+    """nsets=2: detect runs on the library's second stream; the local sum queued right behind
+    pb_process (no fetch, no sync in between, as bench.py --gpus N does) must still see its planes."""
     lp = libpb()
     A, nseg = 3, 2
     datas = [make_input(20 + a, R, nseg) for a in range(A)]
-    with lp.PbHandle(nant=A, nbit=8, rows_per_seg=R, max_seg=nseg, keep_ave=True) as h:
+    import torch
+    with lp.PbHandle(nant=A, nbit=8, rows_per_seg=R, max_seg=nseg, keep_ave=True, nsets=nsets) as h:
+        d_sum = torch.zeros(nseg * h.ave_per_seg, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
         for a in range(A):
             for s in range(nseg):
                 h.submit_planar(a, s, datas[a][s, 0], datas[a][s, 1])
         h.process(nseg)
-        outs = [h.fetch(a, 0, nseg, ave=True) for a in range(A)]
-        import torch
-        d_sum = torch.zeros(nseg * h.ave_per_seg, dtype=torch.float32, device="cuda")
         h.coadd_local(nseg, d_sum.data_ptr())
         h.sync()
         summed = d_sum.cpu().numpy()
+        outs = [h.fetch(a, 0, nseg, ave=True) for a in range(A)]
         codes = h.coadd_finish(nseg, d_sum.data_ptr(), A)
     planes = []
     for a in range(A):

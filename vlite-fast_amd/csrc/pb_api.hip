@@ -770,6 +770,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
             e2 = launch_detect(h, nseg, inject_now);
             t.stop();
         }
+        if (e2 == hipSuccess) e2 = hipEventRecord(h->ev_chan, h->s_det);   // this set's kernels are done
         for (int a = 0; a < h->A && e2 == hipSuccess; ++a)
             for (int st = 0; st < 2 && e2 == hipSuccess; ++st) {
                 if (st == 0 ? h->cfg.rfi_mode == 1 : h->cfg.rfi_mode == 0) continue;
@@ -885,7 +886,8 @@ extern "C" int pb_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumula
     if (!h->cfg.keep_ave) return fail(h, PB_ESTATE, "pb_coadd_local needs keep_ave=1");
     if (nseg < 1 || nseg > h->S) return fail(h, PB_EINVAL, "pb_coadd_local: nseg out of range");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    // (the fp32 planes come from detect, which runs on this same stream)
+    // the fp32 planes come from this set's detect, which may have run on the second stream
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_chan, 0));
     StageTimer t(h, PB_ST_COADD);
     HIPCHK(h, launch_coadd_local(h, nseg, d_sum, accumulate));
     t.stop();
