@@ -467,6 +467,9 @@ extern "C" int pb_reset_bandpass(pb_handle *h, int ant)
     if (!h) return PB_EINVAL;
     if (check_ant(h, ant)) return PB_EINVAL;
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    // the last detect (which may be on the second stream) still owns the bandpass; the next one is
+    // ordered behind this stream by its channeliser's event
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_alldone, 0));
     HIPCHK(h, hipMemsetAsync(h->d_bp + (size_t)ant * 4 * PB_NCHANOUT, 0, 4 * PB_NCHANOUT * sizeof(float), h->stream));
     return PB_OK;
 }
