@@ -192,20 +192,19 @@ def main():
 
     ts = None
     if world > 1:
-        # the library runs on a torch stream so that kernels -> RCCL reduce -> requantise are ordered on
-        # the device, with no host synchronisation inside a step
+        # The incoherent sum has a stream of its own: local sum -> RCCL reduce -> requantise of batch k
+        # are ordered on it by the device (the library makes it wait for detect of batch k with an
+        # event) and run beside the kernels of batch k+1; no host synchronisation inside a step.
         ts = torch.cuda.Stream(device=dev)
         h.sync()
-        h.set_stream(ts.cuda_stream)
+        h.set_coadd_stream(ts.cuda_stream)
 
     def step():
         k = state["k"]
         h.select_set(k % NSETS)
-        if world == 1:
-            h.process(S)
-        else:
+        h.process(S)
+        if world > 1:
             with torch.cuda.stream(ts):
-                h.process(S)
                 h.coadd_local(S, d_sum.data_ptr())
                 if args.dist_backend == "nccl":
                     dist.reduce(d_sum, dst=0, op=dist.ReduceOp.SUM)

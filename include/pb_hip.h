@@ -172,6 +172,11 @@ int pb_output_dev(pb_handle *h, int ant, int stream, void **codes, void **ave);
  * RCCL reduce of d_sum done by the host (torch.distributed); then on the root:
  * codes = sel_and_dig(d_sum / sqrt(nant_total)). */
 int pb_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate);
+/* Run pb_coadd_local / pb_coadd_finish (and so the collective the host queues between them) on
+ * `stream` (a hipStream_t; NULL = the handle's main stream, the default).  On a stream of its own the
+ * sum of batch k, its RCCL reduce and the root's requantisation overlap the kernels of batch k+1;
+ * the library orders them against detect of the same buffer set with events. */
+int pb_set_coadd_stream(pb_handle *h, void *stream);
 int pb_coadd_finish(pb_handle *h, int nseg, const float *d_sum, int nant_total,
                     uint8_t *codes_host);   /* codes_host NULL: asynchronous, see pb_coadd_fetch_ptr */
 /* pinned-host view of the coadded bytes of the latest (age 0) or previous (age 1) pb_coadd_finish */

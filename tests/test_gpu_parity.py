@@ -191,8 +191,8 @@ def test_pfb_taps4_matches_reference_polyphase_filterbank(golden, oracle):
 # ---------------------------------------------------------------------------
 # antenna batching on one GPU + incoherent coadd
 
-@pytest.mark.parametrize("nsets", [1, 2])
-def test_antenna_batch_and_coadd(oracle, nsets):
+@pytest.mark.parametrize("nsets,own_stream", [(1, False), (2, False), (2, True)])
+def test_antenna_batch_and_coadd(oracle, nsets, own_stream):
     """nsets=2: detect runs on the library's second stream; the local sum queued right behind
     pb_process (no fetch, no sync in between, as bench.py --gpus N does) must still see its planes."""
     lp = libpb()
@@ -201,7 +201,10 @@ def test_antenna_batch_and_coadd(oracle, nsets):
     import torch
     with lp.PbHandle(nant=A, nbit=8, rows_per_seg=R, max_seg=nseg, keep_ave=True, nsets=nsets) as h:
         d_sum = torch.zeros(nseg * h.ave_per_seg, dtype=torch.float32, device="cuda")
+        cs = torch.cuda.Stream() if own_stream else None
         torch.cuda.synchronize()
+        if own_stream:                       # the sum (and the collective) on a stream of its own
+            h.set_coadd_stream(cs.cuda_stream)
         for a in range(A):
             for s in range(nseg):
                 h.submit_planar(a, s, datas[a][s, 0], datas[a][s, 1])

@@ -320,12 +320,12 @@ __global__ void k_coadd_local(const float *__restrict__ ave, size_t ant_stride, 
     }
 }
 
-hipError_t launch_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate)
+hipError_t launch_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate, hipStream_t st)
 {
     const int stream = h->cfg.rfi_mode == 0 ? 0 : 1;
     const size_t n = (size_t)nseg * h->ave_per_seg;
     const float *ave = h->d_ave + (size_t)stream * h->S * h->ave_per_seg;
-    k_coadd_local<<<1024, 256, 0, h->stream>>>(ave, (size_t)2 * h->S * h->ave_per_seg, h->A, d_sum, n,
+    k_coadd_local<<<1024, 256, 0, st>>>(ave, (size_t)2 * h->S * h->ave_per_seg, h->A, d_sum, n,
                                                accumulate);
     return hipGetLastError();
 }
@@ -368,9 +368,10 @@ __global__ void k_coadd_digitise(const float *__restrict__ sum, float scale, uin
     }
 }
 
-hipError_t launch_coadd_digitise(pb_handle *h, int nseg, const float *d_sum, float scale, uint8_t *d_codes)
+hipError_t launch_coadd_digitise(pb_handle *h, int nseg, const float *d_sum, float scale, uint8_t *d_codes,
+                                 hipStream_t st)
 {
-    k_coadd_digitise<<<512, 256, 0, h->stream>>>(d_sum, scale, d_codes, h->ave_per_seg, h->trim, nseg,
+    k_coadd_digitise<<<512, 256, 0, st>>>(d_sum, scale, d_codes, h->ave_per_seg, h->trim, nseg,
                                                  h->cfg.npol, h->cfg.nbit, h->R / PB_NSCRUNCH);
     return hipGetLastError();
 }

@@ -16,6 +16,7 @@ static hipError_t sync_all(pb_handle *h)
     hipError_t e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess && h->s_det) e = hipStreamSynchronize(h->s_det);
     if (e == hipSuccess && h->s_kur) e = hipStreamSynchronize(h->s_kur);
+    if (e == hipSuccess && h->s_coadd) e = hipStreamSynchronize(h->s_coadd);
     return e;
 }
 
@@ -151,7 +152,7 @@ static void store_set(pb_handle *h, int i)
     b.d_in = h->d_in; b.d_flags = h->d_flags; b.d_codes = h->d_codes; b.h_codes = h->h_codes;
     b.d_wrow = h->d_wrow; b.d_stats = h->d_stats; b.d_fraw = h->d_fraw; b.d_fkur = h->d_fkur;
     b.d_Praw = h->d_Praw; b.d_Pkur = h->d_Pkur; b.d_ave = h->d_ave; b.d_Xraw = h->d_Xraw; b.d_Xkur = h->d_Xkur;
-    b.ev_chan = h->ev_chan; b.ev_det = h->ev_det; b.processed = h->processed;
+    b.ev_chan = h->ev_chan; b.ev_det = h->ev_det; b.ev_cl = h->ev_cl; b.processed = h->processed;
 }
 
 static void load_set(pb_handle *h, int i)
@@ -160,7 +161,7 @@ static void load_set(pb_handle *h, int i)
     h->d_in = b.d_in; h->d_flags = b.d_flags; h->d_codes = b.d_codes; h->h_codes = b.h_codes;
     h->d_wrow = b.d_wrow; h->d_stats = b.d_stats; h->d_fraw = b.d_fraw; h->d_fkur = b.d_fkur;
     h->d_Praw = b.d_Praw; h->d_Pkur = b.d_Pkur; h->d_ave = b.d_ave; h->d_Xraw = b.d_Xraw; h->d_Xkur = b.d_Xkur;
-    h->ev_chan = b.ev_chan; h->ev_det = b.ev_det; h->processed = b.processed;
+    h->ev_chan = b.ev_chan; h->ev_det = b.ev_det; h->ev_cl = b.ev_cl; h->processed = b.processed;
     h->cur_set = i;
 }
 
@@ -244,6 +245,7 @@ static int create_impl(pb_handle *h)
     }
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_chan, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_det, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_cl, hipEventDisableTiming));
     h->processed = 0;
     store_set(h, si);
     }
@@ -331,7 +333,8 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
     h->frb_amp = 1.f;
     h->d_Xraw = h->d_Xkur = nullptr;
     h->h_codes = nullptr;
-    h->ev_chan = h->ev_det = nullptr;
+    h->ev_chan = h->ev_det = h->ev_cl = nullptr;
+    h->s_coadd = nullptr;
     h->processed = 0;
     h->cur_set = 0;
     h->s_det = nullptr;
@@ -372,6 +375,7 @@ extern "C" void pb_destroy(pb_handle *h)
         if (b.h_codes) (void)hipHostFree(b.h_codes);
         if (b.ev_chan) (void)hipEventDestroy(b.ev_chan);
         if (b.ev_det) (void)hipEventDestroy(b.ev_det);
+        if (b.ev_cl) (void)hipEventDestroy(b.ev_cl);
     }
     if (!stored) {  // pb_create failed half-way through a set: free the loose members
         void *sp[] = {h->d_in, h->d_flags, h->d_codes, h->d_wrow, h->d_stats, h->d_fraw, h->d_fkur,
@@ -767,6 +771,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
     if (overlap_detect && h->sets.size() >= 2 && !hipfft) {
         hipStream_t s_main = h->stream;
         hipError_t e2 = hipStreamWaitEvent(h->s_det, h->ev_fftdone, 0);
+        if (e2 == hipSuccess) e2 = hipStreamWaitEvent(h->s_det, h->ev_cl, 0);   // planes of this set were summed
         h->stream = h->s_det;
         if (e2 == hipSuccess) {
             StageTimer t(h, PB_ST_DETECT);
@@ -789,6 +794,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         return PB_OK;
     }
     {
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_cl, 0));   // planes of this set were summed
         StageTimer t(h, PB_ST_DETECT);
         HIPCHK(h, launch_detect(h, nseg, inject_now));
         t.stop();
@@ -883,17 +889,37 @@ extern "C" int pb_output_dev(pb_handle *h, int ant, int stream, void **codes, vo
     return PB_OK;
 }
 
+extern "C" int pb_set_coadd_stream(pb_handle *h, void *stream)
+{
+    if (!h) return PB_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, sync_all(h));
+    h->s_coadd = (hipStream_t)stream;
+    return PB_OK;
+}
+
 extern "C" int pb_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate)
 {
     if (!h || !d_sum) return PB_EINVAL;
     if (!h->cfg.keep_ave) return fail(h, PB_ESTATE, "pb_coadd_local needs keep_ave=1");
     if (nseg < 1 || nseg > h->S) return fail(h, PB_EINVAL, "pb_coadd_local: nseg out of range");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    // the fp32 planes come from this set's detect, which may have run on the second stream
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_chan, 0));
-    StageTimer t(h, PB_ST_COADD);
-    HIPCHK(h, launch_coadd_local(h, nseg, d_sum, accumulate));
-    t.stop();
+    // The fp32 planes come from this set's detect, which may have run on the second stream.  On a
+    // coadd stream of its own (pb_set_coadd_stream) this wait holds up neither the next batch's
+    // channeliser nor its detect.
+    hipStream_t cs = h->s_coadd ? h->s_coadd : h->stream;
+    HIPCHK(h, hipStreamWaitEvent(cs, h->ev_chan, 0));
+    hipStream_t s_main = h->stream;
+    h->stream = cs;                       // (StageTimer records on h->stream)
+    hipError_t e;
+    {
+        StageTimer t(h, PB_ST_COADD);
+        e = launch_coadd_local(h, nseg, d_sum, accumulate, cs);
+        t.stop();
+    }
+    if (e == hipSuccess) e = hipEventRecord(h->ev_cl, cs);
+    h->stream = s_main;
+    HIPCHK(h, e);
     return PB_OK;
 }
 
@@ -917,14 +943,12 @@ extern "C" int pb_coadd_finish(pb_handle *h, int nseg, const float *d_sum, int n
     h->coadd_slot ^= 1;
     h->coadd_last = slot;
     const float scale = (float)(1.0 / sqrt((double)nant_total));
-    // the slot's previous D2H (two calls ago) must be done before its device buffer is rewritten
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_coadd[slot], 0));
-    HIPCHK(h, launch_coadd_digitise(h, nseg, d_sum, scale, h->d_coadd_codes + slot * nb));
-    HIPCHK(h, hipEventRecord(h->ev_chan, h->stream));
-    HIPCHK(h, hipStreamWaitEvent(h->s_det, h->ev_chan, 0));
-    HIPCHK(h, launch_copy_out(h->h_coadd_codes + slot * nb, h->d_coadd_codes + slot * nb, (size_t)nseg * h->trim,
-                              h->s_det));
-    HIPCHK(h, hipEventRecord(h->ev_coadd[slot], h->s_det));
+    // requantise and copy out on the coadd stream, in order (the slot's previous copy-out, two calls
+    // ago, went through the same stream)
+    hipStream_t cs = h->s_coadd ? h->s_coadd : h->stream;
+    HIPCHK(h, launch_coadd_digitise(h, nseg, d_sum, scale, h->d_coadd_codes + slot * nb, cs));
+    HIPCHK(h, launch_copy_out(h->h_coadd_codes + slot * nb, h->d_coadd_codes + slot * nb, (size_t)nseg * h->trim, cs));
+    HIPCHK(h, hipEventRecord(h->ev_coadd[slot], cs));
     if (codes_host) {
         HIPCHK(h, hipEventSynchronize(h->ev_coadd[slot]));
         memcpy(codes_host, h->h_coadd_codes + slot * nb, (size_t)nseg * h->trim);

@@ -74,12 +74,13 @@ struct pb_handle {
     uint8_t *h_codes;      // pinned mirror of d_codes, filled asynchronously after detect
     hipEvent_t ev_chan;    // kernels of this set done (its D2H may start)
     hipEvent_t ev_det;     // D2H of this set done (set may be refilled / fetched)
+    hipEvent_t ev_cl;      // pb_coadd_local has read this set's fp32 planes (next detect may overwrite)
     int processed;         // segments of the last pb_process on this set
     struct BufSet {
         uint8_t *d_in, *d_flags, *d_codes, *h_codes;
         float *d_wrow, *d_stats, *d_fraw, *d_fkur, *d_Praw, *d_Pkur, *d_ave;
         float2 *d_Xraw, *d_Xkur;
-        hipEvent_t ev_chan, ev_det;
+        hipEvent_t ev_chan, ev_det, ev_cl;
         int processed;
     };
     std::vector<BufSet> sets;
@@ -90,6 +91,7 @@ struct pb_handle {
     int last_set;          // buffer set of the previous pb_process (-1: none)
     uint8_t *d_coadd_codes, *h_coadd_codes;   // [2][S*trim] coadded bytes (device / pinned), lazily
     hipEvent_t ev_coadd[2];
+    hipStream_t s_coadd;   // stream of pb_coadd_local / pb_coadd_finish (nullptr: the main stream)
     int coadd_slot, coadd_last;
     FftTables ft;
     DagConsts dag;
@@ -116,6 +118,6 @@ hipError_t launch_copy_out(uint8_t *host_pinned, const uint8_t *dev, size_t nbyt
 hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_channelize_f32(pb_handle *h, const float *d_x, int nrows, int taps, float2 *d_out);
-hipError_t launch_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate);
+hipError_t launch_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate, hipStream_t st);
 hipError_t launch_coadd_digitise(pb_handle *h, int nseg, const float *d_sum, float scale,
-                                 uint8_t *d_codes);
+                                 uint8_t *d_codes, hipStream_t st);

@@ -52,7 +52,7 @@ class PbTimers(C.Structure):
 EXPORTS = ["pb_config_default", "pb_create", "pb_destroy", "pb_last_error", "pb_query",
            "pb_set_stream", "pb_sync", "pb_reset_bandpass", "pb_reset_history", "pb_get_bandpass", "pb_set_bandpass",
            "pb_submit_planar", "pb_submit_planar_dev", "pb_submit_vdif", "pb_input_dev", "pb_process", "pb_set_frb_params", "pb_select_set", "pb_fetch", "pb_fetch_ptr",
-           "pb_output_dev", "pb_coadd_local", "pb_coadd_finish", "pb_coadd_fetch_ptr", "pb_profile", "pb_get_timers",
+           "pb_output_dev", "pb_coadd_local", "pb_set_coadd_stream", "pb_coadd_finish", "pb_coadd_fetch_ptr", "pb_profile", "pb_get_timers",
            "pb_debug_fetch", "pb_channelize_f32", "pb_version", "pb_search_create", "pb_search_destroy",
            "pb_search_last_error", "pb_search_info", "pb_search_run"]
 
@@ -103,6 +103,7 @@ def load():
     L.pb_fetch_ptr.argtypes = [vp, C.c_int, C.c_int, C.POINTER(u8p)]
     L.pb_output_dev.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp)]
     L.pb_coadd_local.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.pb_set_coadd_stream.argtypes = [vp, vp]
     L.pb_coadd_finish.argtypes = [vp, C.c_int, vp, C.c_int, u8p]
     L.pb_coadd_fetch_ptr.argtypes = [vp, C.c_int, C.POINTER(u8p)]
     L.pb_profile.argtypes = [vp, C.c_int]
@@ -271,6 +272,10 @@ class PbHandle(object):
         kur = np.ascontiguousarray(kur, np.float32)
         assert raw.size == 2 * NCHANOUT and kur.size == 2 * NCHANOUT
         self._chk(self._L.pb_set_bandpass(self._h, ant, _f32(raw), _f32(kur)))
+
+    def set_coadd_stream(self, stream_ptr):
+        """hipStream_t (int) on which coadd_local / coadd_finish run; 0 = the main stream."""
+        self._chk(self._L.pb_set_coadd_stream(self._h, C.c_void_p(stream_ptr or None)))
 
     def coadd_local(self, nseg, d_sum_ptr, accumulate=False):
         self._chk(self._L.pb_coadd_local(self._h, nseg, C.c_void_p(d_sum_ptr), int(accumulate)))
