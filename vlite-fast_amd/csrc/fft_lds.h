@@ -8,7 +8,8 @@
 #define M_HALF 6250
 
 #ifndef FFT_PREFETCH
-#define FFT_PREFETCH 1   // bit 0: pass-2 twiddles, bit 1: pass-3 twiddles requested one barrier early
+#define FFT_PREFETCH 5   // bit 0: pass-2 twiddles requested before pass 1; pass-3 twiddles requested before the
+                         // pass-2 arithmetic (bit 1) or between that arithmetic and its LDS stores (bit 2)
 #endif
 
 namespace {
@@ -141,8 +142,15 @@ __device__ __forceinline__ void dft10(f2 (&v)[10])
 
 // Complex FFT of length 6250 of the sequence whose pass-1 butterfly inputs are already in
 // v (thread tid < 250 holds z[tid + 250 r], r = 0..24).  Result Z[0..6249] in buf (natural order).
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// in_pass3() runs after the pass-3 twiddles have been applied (their registers are free again): the
+// place for the caller to request what it needs right after the transform.
+template <class Hook = NoHook>
 __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restrict__ tw2,
-                                        const f2 *__restrict__ tw3, int tid)
+                                        const f2 *__restrict__ tw3, int tid, Hook in_pass3 = Hook())
 {
     // Twiddles of the next pass are requested BEFORE the barriers that precede their use, so
     // that their L2 latency hides under this pass's arithmetic and LDS traffic.
@@ -195,11 +203,16 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
     load_t3();
 #endif
     if (tid < 250) {
-        const int j0 = (tid / 25) * 625 + k;
 #pragma unroll
         for (int r = 1; r < 25; r += 4)
             cmul4(v[r], v[r + 1], v[r + 2], v[r + 3], t2[r - 1], t2[r], t2[r + 1], t2[r + 2]);
         dft25(v);
+    }
+#if FFT_PREFETCH & 4
+    load_t3();   // after the pass-2 arithmetic (the register peak), before its LDS stores and the barrier
+#endif
+    if (tid < 250) {
+        const int j0 = (tid / 25) * 625 + k;
 #pragma unroll
         for (int r = 0; r < 25; ++r) buf[j0 + 25 * r] = v[r];
     }
@@ -215,7 +228,7 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
             for (int r = 0; r < 10; ++r) u[i][r] = buf[j + 625 * r];
         }
     }
-#if !(FFT_PREFETCH & 2)
+#if !(FFT_PREFETCH & 6)
     load_t3();
 #endif
 #pragma unroll
@@ -225,6 +238,7 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
             cmul4(u[i][1], u[i][2], u[i][3], u[i][4], t3[i][0], t3[i][1], t3[i][2], t3[i][3]);
             cmul4(u[i][5], u[i][6], u[i][7], u[i][8], t3[i][4], t3[i][5], t3[i][6], t3[i][7]);
             u[i][9] = cmul(u[i][9], t3[i][8]);
+            if (i == 0) in_pass3();
             dft10(u[i]);
 #pragma unroll
             for (int r = 0; r < 10; ++r) buf[j + 625 * r] = u[i][r];

@@ -85,7 +85,18 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
         }
     }
     __syncthreads();   // all samples are in registers before pass 1 overwrites buf
-    fft6250(v, buf, (const f2 *)a.tw2, (const f2 *)a.tw3, tid);
+    // The spectrum step's eight twiddle loads are requested from inside pass 3: one L2 latency for the
+    // whole step instead of one per 1024-channel slice, and most of it hidden under pass 3 (the step was
+    // 25-35 % of a workgroup's life, almost all of it waiting).
+    float4 tq[4][2];
+    auto load_tq = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            tq[i][0] = *(const float4 *)(a.postc + tid * 4 + 1024 * i);
+            tq[i][1] = *(const float4 *)(a.postc + tid * 4 + 1024 * i + 2);
+        }
+    };
+    fft6250(v, buf, (const f2 *)a.tw2, (const f2 *)a.tw3, tid, load_tq);
 
     // FRB injection window of this row, per channel (inject_frb :361-380)
     const bool inject = a.frb.delays != nullptr && a.inject_now > 0;
@@ -96,9 +107,10 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
     // four consecutive channels per thread: 16-byte twiddle loads and 16-byte power stores (one
     // channel per lane would spare the 8-way LDS bank conflicts of these reads, but its 4-byte stores
     // measured 9 % slower overall)
-    for (int c4 = tid * 4; c4 < PB_NCHANOUT; c4 += 1024) {
-        const float4 t01 = *(const float4 *)(a.postc + c4);
-        const float4 t23 = *(const float4 *)(a.postc + c4 + 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c4 = tid * 4 + 1024 * i;
+        const float4 t01 = tq[i][0], t23 = tq[i][1];
         const f2 tw[4] = {mk2(t01.x, t01.y), mk2(t01.z, t01.w), mk2(t23.x, t23.y), mk2(t23.z, t23.w)};
         float pw[4];
 #pragma unroll
