@@ -15,6 +15,8 @@
 // back end additionally 4 (+4) B/sample of fp32 voltages written.
 #include "pb_internal.h"
 
+typedef float f2k __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float cvt_sample(unsigned u)
 {
     return u == 0 ? 0.0f : (float)u / 128 - 1;
@@ -66,6 +68,22 @@ __device__ __forceinline__ float4 cvt4(uint32_t w)
     return f;
 }
 
+__device__ __forceinline__ unsigned fix0(unsigned w)
+{
+    const unsigned t = ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w;   // bit 7 of a byte set <=> byte != 0
+    return w | (~t & 0x80808080u);
+}
+__device__ __forceinline__ uint4 fix0(uint4 q) { return make_uint4(fix0(q.x), fix0(q.y), fix0(q.z), fix0(q.w)); }
+
+// r[lane] += r[lane + s] for s = 8, 4, 2, 1 inside a row of 16 lanes (DPP row_shl: lane i reads lane
+// i + s of its row); only lanes < s of the row hold meaningful sums afterwards, lane 0 the total --
+// the same additions in the same order as the reference's halving tree (kurtosis :60-94).
+template <int S> __device__ __forceinline__ float add_row_shl(float r)
+{
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x100 + S, 0xf, 0xf, true);
+    return r + __int_as_float(t);
+}
+
 #define ROW_CHUNKS 784   // 16-byte chunks covering a 12500-byte row at any 4-byte alignment
 
 template <bool WRITE_F32>
@@ -98,14 +116,17 @@ __global__ __launch_bounds__(256) void k_kurtosis_row(
         uint4 a3 = make_uint4(0u, 0u, 0u, 0u), b3 = a3;
         if (h0) a3 = s0[tid + 768];
         if (h1) b3 = s1[tid + 768];
-        sraw[0][tid] = a0; sraw[0][tid + 256] = a1; sraw[0][tid + 512] = a2;
-        sraw[1][tid] = b0; sraw[1][tid + 256] = b1; sraw[1][tid + 512] = b2;
-        if (h0) sraw[0][tid + 768] = a3;
-        if (h1) sraw[1][tid + 768] = b3;
+        // code 0 ("no sample" -> 0.0, convertarray :23-33) is rewritten to code 128 (= 0.0) four bytes
+        // per instruction, so that the conversion below is one fma per pair: u/128 - 1 is exact
+        sraw[0][tid] = fix0(a0); sraw[0][tid + 256] = fix0(a1); sraw[0][tid + 512] = fix0(a2);
+        sraw[1][tid] = fix0(b0); sraw[1][tid + 256] = fix0(b1); sraw[1][tid + 512] = fix0(b2);
+        if (h0) sraw[0][tid + 768] = fix0(a3);
+        if (h1) sraw[1][tid + 768] = fix0(b3);
     }
     __syncthreads();
 
-    // each wave reduces blocks wave, wave+4, ...: leaves t = lane + 64 i hold (x[t]^2, x[t+250]^2)
+    // each wave reduces blocks wave, wave+4, ...: leaves t = lane + 64 i hold (x[t]^2, x[t+250]^2),
+    // the pair side by side in packed-f32 instructions
     for (int bi = wave; bi < 50; bi += 4) {
         const int pol = bi / 25, blk = bi % 25;
         const uint8_t *sb = (const uint8_t *)sraw[pol] + (pol ? off1 : off0) + blk * PB_NKURTO;
@@ -113,28 +134,34 @@ __global__ __launch_bounds__(256) void k_kurtosis_row(
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int t = lane + 64 * i;
-            if (t < 250) {
-                const float x0 = cvt_sample(sb[t]);
-                const float x1 = cvt_sample(sb[t + 250]);
-                const float a = x0 * x0;
-                const float tm = x1 * x1;
-                const float a2 = a * a;
-                const float t2 = tm * tm;
-                d4[i] = a2 + t2;
-                d2[i] = a + tm;
-            } else {
-                d2[i] = 0.f;
-                d4[i] = 0.f;
-            }
+            const bool in = t < 250;
+            const int tt = in ? t : 0;
+            f2k u;
+            u.x = (float)sb[tt];
+            u.y = (float)sb[tt + 250];
+            const f2k k128 = {0.0078125f, 0.0078125f}, m1 = {-1.0f, -1.0f};
+            const f2k x = __builtin_elementwise_fma(u, k128, m1);
+            const f2k a = x * x;
+            const f2k a2 = a * a;
+            const float e4 = a2.x + a2.y, e2 = a.x + a.y;
+            d4[i] = in ? e4 : 0.f;
+            d2[i] = in ? e2 : 0.f;
         }
         // halving tree 128, 64 in registers, then 32..1 across the wave: d[t] += d[t+s]
         float r2 = (d2[0] + d2[2]) + (d2[1] + d2[3]);
         float r4 = (d4[0] + d4[2]) + (d4[1] + d4[3]);
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) {
-            r2 = r2 + __shfl_down(r2, s);
-            r4 = r4 + __shfl_down(r4, s);
-        }
+        r2 = r2 + __shfl_down(r2, 32);
+        r4 = r4 + __shfl_down(r4, 32);
+        r2 = r2 + __shfl_down(r2, 16);
+        r4 = r4 + __shfl_down(r4, 16);
+        r2 = add_row_shl<8>(r2);
+        r4 = add_row_shl<8>(r4);
+        r2 = add_row_shl<4>(r2);
+        r4 = add_row_shl<4>(r4);
+        r2 = add_row_shl<2>(r2);
+        r4 = add_row_shl<2>(r4);
+        r2 = add_row_shl<1>(r2);
+        r4 = add_row_shl<1>(r4);
         if (lane == 0) {
             s2[bi] = r2;
             s4[bi] = r4;
