@@ -99,7 +99,10 @@ enum { PB_DBG_POW = 0,      /* float [2][nblk]   kurtosis `pow`  src/pb_kernels.
        PB_DBG_KUR = 1,      /* float [2][nblk]   `kur`           :105 */
        PB_DBG_DAG = 2,      /* float [2][nblk]   `dag`           :132 */
        PB_DBG_FLAGS = 3,    /* uint8 [nblk]      dag > DAG_THRESH (:256), shared by both pols */
-       PB_DBG_ROWWEIGHT = 4 /* float [rows]      kur_weights after apply_kurtosis (:292) */ };
+       PB_DBG_ROWWEIGHT = 4, /* float [rows]     kur_weights after apply_kurtosis (:292) */
+       PB_DBG_POW_FB = 5,   /* float [2][rows]   block_kurtosis `pow_block` :140-212 (diagnostic, K4) */
+       PB_DBG_KUR_FB = 6,   /* float [2][rows]   block_kurtosis `kur_block` */
+       PB_DBG_DAG_FB = 7    /* float [rows]      compute_dagostino2 over FFT rows :219-241 */ };
 
 void pb_config_default(pb_config *cfg);
 

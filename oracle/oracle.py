@@ -124,6 +124,19 @@ def compute_dagostino(kur, which=0):
     return dag
 
 
+def block_kurtosis(pow_, kur, dag):
+    """K4 (src/pb_kernels.cu:140-212): per-FFT-row pow / kur from the per-block statistics of both
+    pols; returns (pow_block, kur_block), 2 * nrows entries each."""
+    pow_ = np.ascontiguousarray(pow_, np.float32)
+    kur = np.ascontiguousarray(kur, np.float32)
+    dag = np.ascontiguousarray(dag, np.float32)
+    nfft = pow_.size // (NFFT // NKURTO)
+    pb = np.zeros(nfft, np.float32)
+    kb = np.zeros(nfft, np.float32)
+    lib().orc_block_kurtosis(_f(pow_), _f(kur), _f(dag), _f(pb), _f(kb), nfft)
+    return pb, kb
+
+
 def apply_kurtosis(time, dag):
     time = np.ascontiguousarray(time, dtype=np.float32).ravel()
     out = np.empty_like(time)

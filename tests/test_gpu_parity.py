@@ -68,6 +68,25 @@ def test_prefft_statistics_and_flags_exact(oracle, data, oracle_mode2):
     assert (w == 0).any() and ((w > 0) & (w < 1)).any()
 
 
+def test_block_kurtosis_row_statistic(oracle, data, oracle_mode2):
+    """K4: block_kurtosis + compute_dagostino2 (src/pb_kernels.cu:140-241), the per-FFT-row statistic the
+    reference computes and no output uses; kept with debug_keep and bit-exact against the oracle."""
+    lp = libpb()
+    res, _, _ = oracle_mode2
+    nseg = data.shape[0]
+    with lp.PbHandle(nant=1, nbit=8, rfi_mode=2, rows_per_seg=R, max_seg=nseg, debug_keep=True) as h:
+        for s in range(nseg):
+            h.submit_planar(0, s, data[s, 0], data[s, 1])
+        h.process(nseg)
+        for s in range(nseg):
+            pow_fb, kur_fb = oracle.block_kurtosis(res[s].pow, res[s].kur, res[s].dag)
+            dag_fb = oracle.compute_dagostino(kur_fb, which=1)
+            assert _same_bits(h.debug_fetch(lp.DBG_POW_FB, 0, s).ravel(), pow_fb)
+            assert _same_bits(h.debug_fetch(lp.DBG_KUR_FB, 0, s).ravel(), kur_fb)
+            assert _same_bits(h.debug_fetch(lp.DBG_DAG_FB, 0, s), dag_fb[:R])
+            assert np.isfinite(pow_fb).all() and (pow_fb > 0).any()
+
+
 @pytest.mark.parametrize("nbit", [8, 4, 2])
 def test_hipfft_backend_codes(oracle, data, nbit):
     lp = libpb()

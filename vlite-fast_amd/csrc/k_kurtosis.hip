@@ -91,11 +91,13 @@ __global__ __launch_bounds__(256) void k_kurtosis_row(
     const uint8_t *__restrict__ in, size_t in_ant_stride, size_t seg_samples, int R,
     uint8_t *__restrict__ flags, size_t flags_ant_stride, float *__restrict__ wrow_out,
     size_t wrow_ant_stride, float *__restrict__ stats, size_t nblk_cap,
-    float *__restrict__ fraw, float *__restrict__ fkur, int write_raw, DagConsts dc)
+    float *__restrict__ fraw, float *__restrict__ fkur, int write_raw, DagConsts dc, DagConsts dc_fb,
+    float *__restrict__ stats_fb, size_t nrow_cap)
 {
     __shared__ uint4 sraw[2][ROW_CHUNKS];
     __shared__ float s2[50], s4[50], sdag[50];
     __shared__ unsigned sflag[25];
+    __shared__ float spow[50], skur[50], sfb[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int grow = blockIdx.x;  // seg * R + row
     const int ant = blockIdx.y;
@@ -174,6 +176,10 @@ __global__ __launch_bounds__(256) void k_kurtosis_row(
         const float p = s2[tid] / PB_NKURTO;
         const float k = s4[tid] / PB_NKURTO / (p * p);
         sdag[tid] = dag_one(k, dc);
+        if (stats_fb) {
+            spow[tid] = p;
+            skur[tid] = k;
+        }
         if (stats) {
             const size_t ab = (size_t)ant * 6 * nblk_cap;
             stats[ab + (0 * 2 + pol) * nblk_cap + b0 + blk] = p;
@@ -193,6 +199,49 @@ __global__ __launch_bounds__(256) void k_kurtosis_row(
         }
     }
     __syncthreads();
+    if (stats_fb) {
+        // K4: block_kurtosis + compute_dagostino2 (src/pb_kernels.cu:140-241), the statistic over the whole
+        // FFT row.  No output depends on it (apply_kurtosis ignores dag_fb, :255-256), so it is only
+        // computed when the statistics are kept (debug_keep): one lane per pol walks the reference's
+        // 32-slot halving tree as written (25 live slots, lanes 0..15 stay live).
+        if (tid < 2) {
+            float d2[32], d4[32];
+            unsigned wt[32];
+            for (int l = 0; l < 32; ++l) {
+                if (l > 24) {
+                    d2[l] = 0.f; d4[l] = 0.f; wt[l] = 0;
+                    continue;
+                }
+                const float dmax = fmaxf(sdag[l], sdag[25 + l]);
+                const float pw = spow[tid * 25 + l], ku = skur[tid * 25 + l];
+                wt[l] = dmax < 3.0f ? 1u : 0u;
+                const float wf = (float)wt[l];
+                d2[l] = wf * pw;
+                d4[l] = wf * ku * pw * pw;
+            }
+            for (int sft = 16; sft >= 1; sft >>= 1)
+                for (int l = 0; l < 16; ++l) {
+                    d2[l] = d2[l] + d2[l + sft];
+                    d4[l] = d4[l] + d4[l + sft];
+                    wt[l] = (wt[l] + wt[l + sft]) & 0xffu;
+                }
+            float pb = 0.f, kb = 0.f;
+            if (wt[0] > 0) {
+                pb = d2[0] / (float)wt[0];
+                kb = d4[0] / (float)wt[0] / (pb * pb);
+            }
+            sfb[tid] = pb;
+            sfb[2 + tid] = kb;
+        }
+        __syncthreads();
+        if (tid < 2) {
+            const size_t ab = (size_t)ant * 5 * nrow_cap;
+            stats_fb[ab + (0 + tid) * nrow_cap + grow] = sfb[tid];
+            stats_fb[ab + (2 + tid) * nrow_cap + grow] = sfb[2 + tid];
+            if (tid == 0)
+                stats_fb[ab + 4 * nrow_cap + grow] = fmaxf(dag_one(sfb[2], dc_fb), dag_one(sfb[3], dc_fb));
+        }
+    }
     if (tid == 0) {
         // kur_weights after apply_kurtosis (:292): one atomicAdd of 500/12500 per unflagged block;
         // identical addends sum to the same float in any order.  Both pols share the flag, hence
@@ -241,14 +290,18 @@ hipError_t launch_kurtosis_flag(pb_handle *h, int nseg, bool write_f32)
     }
     dim3 grid((unsigned)(nseg * h->R), (unsigned)h->A);
     const size_t wrow_ant = (size_t)h->S * h->R;
+    // row statistics (K4) live behind the six per-block planes of every antenna
+    const size_t nrow_cap = (size_t)h->S * h->R;
+    float *stats_fb = h->d_stats ? h->d_stats + (size_t)h->A * 6 * nblk_cap : nullptr;
     if (write_f32)
         k_kurtosis_row<true><<<grid, 256, 0, h->stream>>>(
             h->d_in, in_ant_stride, h->seg_samples, h->R, h->d_flags, nblk_cap, h->d_wrow, wrow_ant,
-            h->d_stats, nblk_cap, h->d_fraw, h->d_fkur, h->cfg.rfi_mode == 2 ? 1 : 0, h->dag);
+            h->d_stats, nblk_cap, h->d_fraw, h->d_fkur, h->cfg.rfi_mode == 2 ? 1 : 0, h->dag, h->dag_fb, stats_fb,
+            nrow_cap);
     else
         k_kurtosis_row<false><<<grid, 256, 0, h->stream>>>(
             h->d_in, in_ant_stride, h->seg_samples, h->R, h->d_flags, nblk_cap, h->d_wrow, wrow_ant,
-            h->d_stats, nblk_cap, nullptr, nullptr, 0, h->dag);
+            h->d_stats, nblk_cap, nullptr, nullptr, 0, h->dag, h->dag_fb, stats_fb, nrow_cap);
     return hipGetLastError();
 }
 

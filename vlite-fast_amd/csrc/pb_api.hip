@@ -222,7 +222,7 @@ static int create_impl(pb_handle *h)
         std::vector<float> ones(A * S * R, 1.0f);
         HIPCHK(h, hipMemcpy(h->d_wrow, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    if (c.debug_keep) HIPCHK(h, dmalloc(h, &h->d_stats, A * 6 * S * h->nblk_seg));
+    if (c.debug_keep) HIPCHK(h, dmalloc(h, &h->d_stats, A * 6 * S * h->nblk_seg + A * 5 * S * R));
     const bool need_raw = c.rfi_mode != 1, need_kur = c.rfi_mode != 0;
     if (c.fft_backend == PB_FFT_HIPFFT) {
         if (need_raw) HIPCHK(h, dmalloc(h, &h->d_fraw, in_elems));
@@ -286,6 +286,7 @@ static int create_impl(pb_handle *h)
         HIPCHK(h, hipMemcpy(h->d_tapE, E.data(), 101 * sizeof(float), hipMemcpyHostToDevice));
     }
     h->dag = make_dag((float)PB_NKURTO);
+    h->dag_fb = make_dag((float)PB_NFFT);
     return PB_OK;
 }
 
@@ -1009,6 +1010,18 @@ extern "C" int pb_debug_fetch(pb_handle *h, int what, int ant, int seg, void *ds
             const float *src = h->d_stats + (size_t)ant * 6 * cap + ((size_t)what * 2 + pol) * cap + (size_t)seg * nb;
             HIPCHK(h, hipMemcpy((float *)dst + pol * nb, src, nb * sizeof(float), hipMemcpyDeviceToHost));
         }
+        return PB_OK;
+    }
+    if (what == PB_DBG_POW_FB || what == PB_DBG_KUR_FB || what == PB_DBG_DAG_FB) {
+        if (!h->d_stats) return fail(h, PB_ESTATE, "pb_debug_fetch: statistics need debug_keep=1");
+        const size_t rcap = (size_t)h->S * h->R;
+        const float *fb = h->d_stats + (size_t)h->A * 6 * cap + (size_t)ant * 5 * rcap;
+        const int npl = what == PB_DBG_DAG_FB ? 1 : 2;
+        const int first = what == PB_DBG_POW_FB ? 0 : (what == PB_DBG_KUR_FB ? 2 : 4);
+        if (nbytes != (size_t)npl * h->R * sizeof(float)) return fail(h, PB_EINVAL, "pb_debug_fetch: size");
+        for (int pl = 0; pl < npl; ++pl)
+            HIPCHK(h, hipMemcpy((float *)dst + (size_t)pl * h->R, fb + (size_t)(first + pl) * rcap + (size_t)seg * h->R,
+                                (size_t)h->R * sizeof(float), hipMemcpyDeviceToHost));
         return PB_OK;
     }
     if (what == PB_DBG_FLAGS) {

@@ -94,7 +94,7 @@ struct pb_handle {
     hipStream_t s_coadd;   // stream of pb_coadd_local / pb_coadd_finish (nullptr: the main stream)
     int coadd_slot, coadd_last;
     FftTables ft;
-    DagConsts dag;
+    DagConsts dag, dag_fb;   // D'Agostino constants for N = 500 (blocks) and N = 12500 (FFT rows, K4)
     std::map<long, hipfftHandle> plans;
 
     bool profile;

@@ -23,7 +23,7 @@ FFT_LDS = 0
 FFT_HIPFFT = 1
 
 STAGES = ("kurtosis", "channelize", "fft", "inject", "detect", "deframe", "coadd", "h2d")
-DBG_POW, DBG_KUR, DBG_DAG, DBG_FLAGS, DBG_ROWWEIGHT = range(5)
+DBG_POW, DBG_KUR, DBG_DAG, DBG_FLAGS, DBG_ROWWEIGHT, DBG_POW_FB, DBG_KUR_FB, DBG_DAG_FB = range(8)
 
 
 class PbError(RuntimeError):
@@ -307,6 +307,8 @@ class PbHandle(object):
             a = np.empty((2, self.nblk), np.float32)
         elif what == DBG_FLAGS:
             a = np.empty(self.nblk, np.uint8)
+        elif what in (DBG_POW_FB, DBG_KUR_FB):
+            a = np.empty((2, self.rows), np.float32)
         else:
             a = np.empty(self.rows, np.float32)
         self._chk(self._L.pb_debug_fetch(self._h, what, ant, seg, a.ctypes.data_as(C.c_void_p), a.nbytes))
