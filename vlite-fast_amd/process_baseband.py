@@ -111,6 +111,18 @@ class Log(object):
             fp.flush()
 
 
+def _pinned_bytes(n):
+    """n bytes of page-locked host memory as a numpy array (plain numpy if torch cannot provide it)."""
+    try:
+        import torch
+        t = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+        a = t.numpy()                   # shares the tensor's storage and keeps it alive
+        return a
+    except Exception:
+        return np.empty(n, np.uint8)
+
+
+
 def open_control_socket():
     """Non-blocking membership of 224.3.29.71:20000 (src/utils.c:619, process_baseband.cu:764)."""
     try:
@@ -166,6 +178,7 @@ def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None):
                              rows_per_seg=R, max_seg=SEG_PER_SEC, inject_frb=args.inject_frb)
     trim = handle.trim
     ctl = None if args.no_control else open_control_socket()
+    blocks = None          # page-locked staging for one second of frames, allocated once
     tsamp = 12500.0 / 128e6 * 8
     exit_status, quit_ = 0, False
     written_files = []
@@ -182,7 +195,12 @@ def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None):
         hdr = vdif.ascii_header_parse(raw_hdr)
         log("INFO", "Beginning new observation.")
         handle.reset_history(0)          # taps=4: the FIR window does not span observations
-        block = np.empty(sec_bytes, np.uint8)
+        # One second of frames is assembled in page-locked memory (two buffers, alternating: the H2D of
+        # second k is known to be complete once its filterbank bytes have been fetched), read straight
+        # into place where the ring supports it -- one copy from the ring instead of three.
+        if blocks is None:
+            blocks = [_pinned_bytes(sec_bytes), _pinned_bytes(sec_bytes)]
+        readinto = getattr(in_ring, "readinto", None)
         first = in_ring.read(vdif.VD_FRM)
         if len(first) != vdif.VD_FRM:
             log("ERR", "Problem reading first bloody frame!  Bailing.")
@@ -237,14 +255,20 @@ def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None):
         pending = first        # first frame of the second being assembled
         while True:
             # assemble one second: the pending frame + the rest of the block
+            block = blocks[integrated_sec % 2]
             block[:vdif.VD_FRM] = np.frombuffer(pending, np.uint8)
-            rest = in_ring.read(sec_bytes - vdif.VD_FRM)
-            if len(rest) != sec_bytes - vdif.VD_FRM:
-                if len(rest) % vdif.VD_FRM:
+            if readinto is not None:
+                nrest = readinto(block[vdif.VD_FRM:]) or 0
+            else:
+                rest = in_ring.read(sec_bytes - vdif.VD_FRM)
+                nrest = len(rest)
+                if nrest == sec_bytes - vdif.VD_FRM:
+                    block[vdif.VD_FRM:] = np.frombuffer(rest, np.uint8)
+            if nrest != sec_bytes - vdif.VD_FRM:
+                if nrest % vdif.VD_FRM:
                     log("INFO", "Packet size=%d, expected %d.  Aborting this observation."
-                        % (len(rest) % vdif.VD_FRM, vdif.VD_FRM))
+                        % (nrest % vdif.VD_FRM, vdif.VD_FRM))
                 break                                   # partial final second: dropped
-            block[vdif.VD_FRM:] = np.frombuffer(rest, np.uint8)
             # a second is dispatched only when a frame of the next second has arrived
             nxt = in_ring.read(vdif.VD_FRM)
             if len(nxt) != vdif.VD_FRM:
