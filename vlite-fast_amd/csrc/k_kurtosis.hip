@@ -305,9 +305,6 @@ hipError_t launch_kurtosis_flag(pb_handle *h, int nseg, bool write_f32)
     return hipGetLastError();
 }
 
-// row weights are produced by k_kurtosis_row itself
-hipError_t launch_row_weights(pb_handle *, int) { return hipSuccess; }
-
 // Gather 5000-byte VDIF payloads of one raw ring block into the pol-planar segment layout
 // (replaces the host loop src/process_baseband.cu:1015-1067).  idx[thread][frame] = slot of
 // that frame in the block, or -1 (zero fill).

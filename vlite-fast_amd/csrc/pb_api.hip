@@ -94,10 +94,7 @@ static float2 cis_neg(double num, double den)
 
 static int build_fft_tables(pb_handle *h)
 {
-    std::vector<float2> w25(25), w10(5), tw2(625), tw3(6250), post(PB_NCHAN);
-    for (int a = 0; a < 5; ++a)
-        for (int b = 0; b < 5; ++b) w25[a * 5 + b] = cis_neg((double)(a * b), 25.0);
-    for (int k = 0; k < 5; ++k) w10[k] = cis_neg((double)k, 10.0);
+    std::vector<float2> tw2(625), tw3(6250), post(PB_NCHAN);
     for (int r = 0; r < 25; ++r)
         for (int k = 0; k < 25; ++k) tw2[r * 25 + k] = cis_neg((double)(r * k), 625.0);
     for (int r = 0; r < 10; ++r)
@@ -107,22 +104,14 @@ static int build_fft_tables(pb_handle *h)
         post[k] = make_float2((float)(-sin(a)), (float)(-cos(a)));
     }
     FftTables &t = h->ft;
-    HIPCHK(h, dmalloc(h, &t.w25, 25));
-    HIPCHK(h, dmalloc(h, &t.w10, 5));
     HIPCHK(h, dmalloc(h, &t.tw2, 625));
     HIPCHK(h, dmalloc(h, &t.tw3, 6250));
     HIPCHK(h, dmalloc(h, &t.post, PB_NCHAN));
-    HIPCHK(h, hipMemcpy(t.w25, w25.data(), 25 * sizeof(float2), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(t.w10, w10.data(), 5 * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(t.tw2, tw2.data(), 625 * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(t.tw3, tw3.data(), 6250 * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(t.post, post.data(), PB_NCHAN * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(h, &t.postc, (size_t)PB_NCHANOUT));
     HIPCHK(h, hipMemcpy(t.postc, post.data() + PB_CHANMIN, PB_NCHANOUT * sizeof(float2), hipMemcpyHostToDevice));
-    t.c1 = (float)cos(2.0 * M_PI / 5.0);
-    t.c2 = (float)cos(4.0 * M_PI / 5.0);
-    t.s1 = (float)sin(2.0 * M_PI / 5.0);
-    t.s2 = (float)sin(4.0 * M_PI / 5.0);
     // 4-tap Hamming WOLA taps of analysis/baseband.py:1207-1232 (always built: 200 KB):
     // tap j = window[j ns : (j+1) ns] * norms[0] * (j ? norms[j] : 1), evaluated in double
     {
@@ -189,8 +178,6 @@ static int create_impl(pb_handle *h)
     HIPCHK(h, hipSetDevice(c.device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->own_stream = true;
-    HIPCHK(h, hipEventCreate(&h->ev0));
-    HIPCHK(h, hipEventCreate(&h->ev1));
     {
         // detect is latency-bound and small (one workgroup per CU): give its stream the highest
         // priority so that its workgroups slot in between the channeliser's as CUs free up
@@ -347,7 +334,6 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
     h->coadd_slot = h->coadd_last = 0;
     memset(&h->ft, 0, sizeof h->ft);
     h->profile = false;
-    h->ev0 = h->ev1 = nullptr;
     memset(&h->timers, 0, sizeof h->timers);
     int rc = create_impl(h);
     if (rc != PB_OK) {
@@ -386,7 +372,7 @@ extern "C" void pb_destroy(pb_handle *h)
         if (h->h_codes) (void)hipHostFree(h->h_codes);
     }
     void *ptrs[] = {h->d_vdif, h->d_frame_idx, h->d_bp, h->d_frb_delays, h->d_hist_in, h->d_hist_flags,
-                    h->d_hist_valid, h->d_tapE, h->ft.w25, h->ft.w10, h->ft.tw2,
+                    h->d_hist_valid, h->d_tapE, h->ft.tw2,
                     h->ft.tw3, h->ft.post, h->ft.postc, h->ft.taps};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -401,8 +387,6 @@ extern "C" void pb_destroy(pb_handle *h)
     if (h->ev_alldone) (void)hipEventDestroy(h->ev_alldone);
     drain_timers(h);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -736,7 +720,6 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         if (e == hipSuccess) {
             StageTimer t(h, PB_ST_KURTOSIS);
             e = launch_kurtosis_flag(h, nseg, hipfft);
-            if (e == hipSuccess && h->cfg.rfi_mode) e = launch_row_weights(h, nseg);
             t.stop();
         }
         if (overlap) {

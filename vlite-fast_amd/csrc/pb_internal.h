@@ -25,16 +25,14 @@ struct FrbParams {
     float amp;
 };
 
-// twiddle tables of the LDS FFT (all float2, built on the host in double)
+// twiddle tables of the LDS FFT (all float2, built on the host in double); the radix-5/25/10 twiddles
+// are compile-time literals (fft_consts.h)
 struct FftTables {
-    float2 *w25;    // [5][5]
-    float2 *w10;    // [5]
     float2 *tw2;    // [25][25]  (r, k)
     float2 *tw3;    // [10][625]
     float2 *post;   // [6251]
     float2 *postc;  // [4096] = post[2155..6250], its own 16-byte aligned allocation
     float *taps;    // [4][12500] FIR taps (taps=4) or nullptr
-    float c1, c2, s1, s2;
 };
 
 struct pb_handle {
@@ -98,7 +96,6 @@ struct pb_handle {
     std::map<long, hipfftHandle> plans;
 
     bool profile;
-    hipEvent_t ev0, ev1;
     pb_timers timers;
     struct Pending { int stage; hipEvent_t a, b; };
     std::vector<Pending> pending;        // recorded, not yet read back
@@ -108,7 +105,6 @@ struct pb_handle {
 
 // ---- launchers (each enqueues on h->stream and returns a hipError_t) ----
 hipError_t launch_kurtosis_flag(pb_handle *h, int nseg, bool write_f32);
-hipError_t launch_row_weights(pb_handle *h, int nseg);
 hipError_t launch_deframe(pb_handle *h, int ant, int seg0, size_t nframes_per_thread);
 hipError_t launch_inject_c64(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_detect(pb_handle *h, int nseg, int inject_now);
