@@ -1,206 +1,38 @@
-// Square-law detect + running-bandpass normalise + pol scrunch + time scrunch + requantise.
+// hipFFT back end: square-law detect of the complex spectra into the compact power planes that
+// k_detect2 consumes (the same planes the LDS channeliser writes), FRB injection on complex planes,
+// the device-to-pinned-host copy kernel and the incoherent-sum helpers.
 //
-// One pass over the channelised data replaces, for each of the two output streams,
-//   detect_and_normalize2 / 3   src/pb_kernels.cu:393-429 / :431-511
-//   pscrunch / pscrunch_weights :514-524 / :527-560
-//   tscrunch / tscrunch_weights :564-589 / :591-630
-//   sel_and_dig_8b / 4b / 2b    :711-735 / :672-708 / :633-669
-// restricted to the 4096 output channels (bins 2155..6250).
-//
-// The bandpass is a serial-in-time recurrence per (channel, pol, stream) with a clip
-// branch in the excised stream (:493), so time cannot be parallelised without changing
-// results.  Mapping: one wave = 32 channels x 2 pols of one stream; the partner pol's
-// sample is one cross-lane exchange away, rows are streamed through registers CH rows
-// ahead, and the GPU is filled by (channel groups) x (streams) x (antennas).
-// HBM traffic: 4 B (power plane) or 8 B (complex plane) per (row, channel, pol, stream)
-// read once; outputs are 1/64 of that.
+//   detect_and_normalize2 / 3 (detect part)  src/pb_kernels.cu:393-429 / :431-511
+//   inject_frb                                :347-391
 #include "pb_internal.h"
 
-struct DetectArgs {
-    const void *in[2];       // per stream; float power [..][4096] or float2 spectra [..][6251]
-    size_t ant_stride;       // elements
-    size_t seg_stride;
-    size_t pol_stride;
-    size_t row_stride;
-    int chan_off;            // 2155 for complex planes, 0 for compact power planes
-    const float *wrow;       // [A][wrow_ant_stride]
-    size_t wrow_ant_stride;
-    float *bp;               // [A][2][2][4096]
-    uint8_t *codes;          // [A][2][S][trim]
-    float *ave;              // [A][2][S][ave_per_seg] or nullptr
-    size_t trim, ave_per_seg;
-    int S, R, nseg, npol, nbit, first_stream;
-    float scale, oms, tscale;
-};
-
-template <bool IN_C64> struct InT { typedef float type; };
-template <> struct InT<true> { typedef float2 type; };
-
-template <bool IN_C64>
-__device__ __forceinline__ float power_of(typename InT<IN_C64>::type v);
-template <> __device__ __forceinline__ float power_of<true>(float2 v)
+// P[row][c] = |X[row][2155 + c]|^2 (raw stream) or that over the row weight (excised stream; +inf
+// for rows of weight 0, the convention of k_channelize.hip / k_detect2.hip).  One thread = four
+// channels: 8-byte loads (rows of 6251 complex are only 8-byte aligned), one 16-byte store.
+__global__ __launch_bounds__(256) void k_power_c64(const float2 *__restrict__ X, float *__restrict__ P,
+                                                   const float *__restrict__ wrow, size_t nrowpol, int R, int kur)
 {
-    const float xx = v.x * v.x;
-    const float yy = v.y * v.y;
-    return xx + yy;
-}
-template <> __device__ __forceinline__ float power_of<false>(float v) { return v; }
-
-template <bool IN_C64, int CH>
-__global__ __launch_bounds__(64) void k_detect(DetectArgs a)
-{
-    typedef typename InT<IN_C64>::type T;
-    const int lane = threadIdx.x;
-    const int pol = lane >> 5;
-    const int c = blockIdx.x * 32 + (lane & 31);
-    const int stream = a.first_stream + blockIdx.y;  // 0 = raw (dn2), 1 = excised (dn3)
-    const int ant = blockIdx.z;
-    const bool kur = stream == 1;
-    const int R = a.R;
-    const int cps = R / CH;  // chunks per segment
-
-    const T *in = (const T *)a.in[stream] + (size_t)ant * a.ant_stride + (size_t)pol * a.pol_stride +
-                  a.chan_off + c;
-    const float *wrow = a.wrow + (size_t)ant * a.wrow_ant_stride;
-    float *bpp = a.bp + (((size_t)ant * 2 + stream) * 2 + pol) * PB_NCHANOUT + c;
-    uint8_t *codes = a.codes + ((size_t)ant * 2 + stream) * a.S * a.trim;
-    float *ave = a.ave ? a.ave + ((size_t)ant * 2 + stream) * a.S * a.ave_per_seg : nullptr;
-    const int ntime = R / PB_NSCRUNCH;
-
-    float bp = *bpp;
-    float acc = 0.f;
-    int wt_sum = 0;
-    float wt_sumf = 0.f;
-
-    T cur[CH], nxt[CH];
-    const int nchunk = a.nseg * cps;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // (rowpol, quad of channels)
+    const size_t rp = i / (PB_NCHANOUT / 4);
+    if (rp >= nrowpol) return;
+    const int c4 = (int)(i % (PB_NCHANOUT / 4)) * 4;
+    const float2 *x = X + rp * PB_NCHAN + PB_CHANMIN + c4;
+    float pw[4];
 #pragma unroll
-    for (int j = 0; j < CH; ++j) nxt[j] = in[(size_t)j * a.row_stride];
-
-    for (int k = 0; k < nchunk; ++k) {
-        const int seg = k / cps, row0 = (k % cps) * CH;
-#pragma unroll
-        for (int j = 0; j < CH; ++j) cur[j] = nxt[j];
-        if (k + 1 < nchunk) {
-            const int k1 = k + 1;
-            const T *p = in + (size_t)(k1 / cps) * a.seg_stride + (size_t)((k1 % cps) * CH) * a.row_stride;
-#pragma unroll
-            for (int j = 0; j < CH; ++j) nxt[j] = p[(size_t)j * a.row_stride];
-        }
-        const float *wseg = wrow + (size_t)seg * R;
-
-        if (row0 == 0 && bp == 0.f) {
-            // initialise the bandpass from this segment's mean (:406-411, :444-461)
-            const T *p = in + (size_t)seg * a.seg_stride;
-            if (!kur) {
-                for (int t = 0; t < R; ++t) bp += power_of<IN_C64>(p[(size_t)t * a.row_stride]);
-                bp /= (float)R;
-            } else {
-                int good = 0;
-                for (int t = 0; t < R; ++t) {
-                    const float w = wseg[t];
-                    if (w == 0.f) continue;
-                    good++;
-                    bp += power_of<IN_C64>(p[(size_t)t * a.row_stride]) / w;
-                }
-                if (good == 0) bp = 1.f;
-                else bp /= (float)good;
-            }
-        }
-
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int row = row0 + j;
-            const float pw = power_of<IN_C64>(cur[j]);
-            float w = 1.f;
-            float x;
-            if (!kur) {
-                const float t1 = a.scale * pw;
-                const float t2 = a.oms * bp;
-                bp = t1 + t2;
-                x = pw / bp - 1.f;
-            } else {
-                w = wseg[row];
-                if (w == 0.f) {
-                    x = 0.f;
-                } else {
-                    const float pk = (w == 1.f) ? pw : pw / w;
-                    if (pk > bp * 11.f) {
-                        x = 10.f;
-                    } else {
-                        const float t1 = a.scale * pk;
-                        const float t2 = a.oms * bp;
-                        bp = t1 + t2;
-                        x = pk / bp - 1.f;
-                    }
-                }
-            }
-            // polarisation scrunch
-            float p = x;
-            float wt = w;  // weight tscrunch_weights sees for this row
-            if (a.npol == 1) {
-                const float xo = __shfl_xor(x, 32);
-                const float s = x + xo;
-                if (!kur) {
-                    p = (float)(M_SQRT1_2 * (double)s);
-                } else if ((double)w >= 0.2) {  // both pols carry the same row weight
-                    p = (float)(M_SQRT1_2 * (double)s);
-                    wt = (float)(0.5 * (double)(w + w));
-                } else {
-                    p = 0.f;
-                    wt = 0.f;
-                }
-            }
-            // time scrunch
-            if (!kur) {
-                acc += p;
-            } else if (!((double)wt < 0.2)) {
-                wt_sum++;
-                wt_sumf += wt;
-                const float prod = wt * p;
-                acc += prod;
-            }
-            if ((row & (PB_NSCRUNCH - 1)) == PB_NSCRUNCH - 1) {
-                if (!kur) {
-                    acc *= a.tscale;
-                } else {
-                    if ((double)(wt_sumf / PB_NSCRUNCH) >= 0.2) acc /= sqrtf((float)wt_sum);
-                    else acc = 0.f;
-                }
-                const int trow = row >> 3;
-                // sample index within the segment, as sel_and_dig_* lays it out
-                const size_t n = (a.npol == 1) ? (size_t)trow * PB_NCHANOUT + c
-                                               : ((size_t)trow * 2 + pol) * PB_NCHANOUT + c;
-                const bool writer = (a.npol == 2) || (pol == 0);
-                if (ave && writer) {
-                    const size_t ai = (a.npol == 1) ? n : ((size_t)pol * ntime + trow) * PB_NCHANOUT + c;
-                    ave[(size_t)seg * a.ave_per_seg + ai] = acc;
-                }
-                uint8_t *cseg = codes + (size_t)seg * a.trim;
-                if (a.nbit == 8) {
-                    const float tmp = (float)((double)acc / 0.02957 + 127.5);
-                    const uint8_t q = tmp <= 0 ? 0 : (tmp >= 255 ? 255 : (uint8_t)tmp);
-                    if (writer) cseg[n] = q;
-                } else if (a.nbit == 4) {
-                    const float tmp = (float)((double)acc / 0.3188 + 7.5);
-                    const unsigned q = tmp <= 0 ? 0u : (tmp >= 15 ? 15u : (unsigned)(uint8_t)tmp);
-                    const unsigned hi = __shfl_down(q, 1);
-                    if (writer && !(lane & 1)) cseg[n >> 1] = (uint8_t)(q | (hi << 4));
-                } else {
-                    const double t = (double)acc;
-                    const unsigned q = t < -0.6109 ? 0u : (t < 0.3970 ? 1u : (t < 1.4050 ? 2u : 3u));
-                    const unsigned q1 = __shfl_down(q, 1);
-                    const unsigned q2 = __shfl_down(q, 2);
-                    const unsigned q3 = __shfl_down(q, 3);
-                    if (writer && !(lane & 3)) cseg[n >> 2] = (uint8_t)(q | (q1 << 2) | (q2 << 4) | (q3 << 6));
-                }
-                acc = 0.f;
-                wt_sum = 0;
-                wt_sumf = 0.f;
-            }
-        }
+    for (int q = 0; q < 4; ++q) {
+        const float2 v = x[q];
+        const float xx = v.x * v.x;
+        const float yy = v.y * v.y;
+        pw[q] = xx + yy;
     }
-    *bpp = bp;
+    if (kur) {
+        // rp = ((ant * S + seg) * 2 + pol) * R + row  ->  weight index (ant * S + seg) * R + row
+        const size_t as = rp / ((size_t)2 * R);
+        const float w = wrow[as * R + rp % R];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pw[q] = w == 0.f ? __builtin_inff() : pw[q] / w;
+    }
+    *(float4 *)(P + rp * PB_NCHANOUT + c4) = make_float4(pw[0], pw[1], pw[2], pw[3]);
 }
 
 // inject_frb on complex planes, src/pb_kernels.cu:348-391 (hipFFT back end; the LDS back
@@ -275,37 +107,25 @@ hipError_t launch_copy_out(uint8_t *host_pinned, const uint8_t *dev, size_t nbyt
 
 hipError_t launch_detect(pb_handle *h, int nseg, int)
 {
-    if (h->cfg.fft_backend != PB_FFT_HIPFFT) return launch_detect_pow(h, nseg);
-    DetectArgs a;
-    a.in[0] = h->d_Xraw;
-    a.in[1] = h->d_Xkur;
-    a.row_stride = PB_NCHAN;
-    a.chan_off = PB_CHANMIN;
-    a.pol_stride = (size_t)h->R * a.row_stride;
-    a.seg_stride = 2 * a.pol_stride;
-    a.ant_stride = (size_t)h->S * a.seg_stride;
-    a.wrow = h->d_wrow;
-    a.wrow_ant_stride = (size_t)h->S * h->R;
-    a.bp = h->d_bp;
-    a.codes = h->d_codes;
-    a.ave = h->cfg.keep_ave ? h->d_ave : nullptr;
-    a.trim = h->trim;
-    a.ave_per_seg = h->ave_per_seg;
-    a.S = h->S;
-    a.R = h->R;
-    a.nseg = nseg;
-    a.npol = h->cfg.npol;
-    a.nbit = h->cfg.nbit;
-    a.first_stream = h->cfg.rfi_mode == 1 ? 1 : 0;
-    const double tsamp = (double)PB_NFFT / 128000000 * PB_NSCRUNCH;  // src/process_baseband.cu:739-741
-    a.scale = (float)(tsamp / 1.0);
-    a.oms = 1 - a.scale;
-    a.tscale = (float)sqrt(1. / PB_NSCRUNCH);
-    const int nstreams = h->cfg.rfi_mode == 2 ? 2 : 1;
-    dim3 grid(PB_NCHANOUT / 32, nstreams, h->A);
-    if ((h->R % 32) == 0) k_detect<true, 32><<<grid, 64, 0, h->stream>>>(a);
-    else k_detect<true, 8><<<grid, 64, 0, h->stream>>>(a);
-    return hipGetLastError();
+    if (h->cfg.fft_backend == PB_FFT_HIPFFT) {
+        // complex spectra -> power planes of the segments just transformed (all antennas at once when
+        // the whole handle is processed, else antenna by antenna: planes are [A][S][2][R][...])
+        const size_t per_ant = (size_t)nseg * 2 * h->R;
+        for (int st = 0; st < 2; ++st) {
+            if (st == 0 ? h->cfg.rfi_mode == 1 : h->cfg.rfi_mode == 0) continue;
+            const float2 *X = st ? h->d_Xkur : h->d_Xraw;
+            float *P = st ? h->d_Pkur : h->d_Praw;
+            for (int ant = 0; ant < h->A; ++ant) {
+                const size_t rp0 = (size_t)ant * h->S * 2 * h->R;
+                const size_t nthreads = per_ant * (PB_NCHANOUT / 4);
+                k_power_c64<<<(unsigned)((nthreads + 255) / 256), 256, 0, h->stream>>>(
+                    X + rp0 * PB_NCHAN, P + rp0 * PB_NCHANOUT, h->d_wrow + (size_t)ant * h->S * h->R, per_ant, h->R, st);
+            }
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return launch_detect_pow(h, nseg);
 }
 
 // ---- incoherent coadd helpers (pb_coadd_local / pb_coadd_finish) ----

@@ -217,7 +217,9 @@ static int create_impl(pb_handle *h)
         const size_t xn = A * S * 2 * R * PB_NCHAN;
         if (need_raw) HIPCHK(h, dmalloc(h, &h->d_Xraw, xn));
         if (need_kur) HIPCHK(h, dmalloc(h, &h->d_Xkur, xn));
-    } else {
+    }
+    {
+        // power planes: written by the LDS channeliser, or from the complex spectra of hipFFT
         const size_t pn = A * S * 2 * R * PB_NCHANOUT;
         if (need_raw) HIPCHK(h, dmalloc(h, &h->d_Praw, pn));
         if (need_kur) HIPCHK(h, dmalloc(h, &h->d_Pkur, pn));
