@@ -143,25 +143,35 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
         }
     }
     __syncthreads();
-    fft6250(v, buf, (const f2 *)a.tw2, (const f2 *)a.tw3, tid);
+    // the spectrum step's twiddles are requested from inside pass 3 (as in k_channelize.hip)
+    float4 tq[4][2];
+    auto load_tq = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            tq[i][0] = *(const float4 *)(a.postc + tid * 4 + 1024 * i);
+            tq[i][1] = *(const float4 *)(a.postc + tid * 4 + 1024 * i + 2);
+        }
+    };
+    fft6250(v, buf, (const f2 *)a.tw2, (const f2 *)a.tw3, tid, load_tq);
 
     const bool inject = a.frb.delays != nullptr && a.inject_now > 0;
     const int since = inject ? (a.inject_now - 1 + seg) * a.R : 0;
     const bool also_kur = a.rfi_mode == 2 && role == 0 && differ == 0;
     float *P0 = (role == 1 ? a.Pkur : a.Praw) + prow;
     float *P1 = a.Pkur + prow;
-    for (int c4 = tid * 4; c4 < PB_NCHANOUT; c4 += 1024) {
-        const float4 t01 = *(const float4 *)(a.postc + c4);
-        const float4 t23 = *(const float4 *)(a.postc + c4 + 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c4 = tid * 4 + 1024 * i;
+        const float4 t01 = tq[i][0], t23 = tq[i][1];
         const f2 tw[4] = {mk2(t01.x, t01.y), mk2(t01.z, t01.w), mk2(t23.x, t23.y), mk2(t23.z, t23.w)};
         float pw[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = PB_CHANMIN + c4 + q;
             const f2 za = buf[k == M_HALF ? 0 : k];
-            f2 zb = buf[M_HALF - k];
-            zb.y = -zb.y;
-            const f2 E = za + zb, O = za - zb;
+            const f2 zb = buf[M_HALF - k];
+            f2 E, O;
+            addsub_conj(za, zb, E, O);
             const f2 Pq = cmul(O, tw[q]);
             f2 X = mk2(0.5f, 0.5f) * (E + Pq);
             if (inject) {
