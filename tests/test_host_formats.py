@@ -132,6 +132,37 @@ def test_memory_and_file_rings(tmp_path):
         dada.open_ring(0x40)
 
 
+def test_file_ring_over_a_fifo(tmp_path):
+    """A FIFO fed in small pieces (how a psrdada bridge process would deliver a live ring): requests are
+    still filled completely, readinto fills a staging array in place, EOF gives a short read."""
+    import os
+    import threading
+    path = str(tmp_path / "ring.fifo")
+    os.mkfifo(path)
+    hdr = b"STATIONID 7\n".ljust(4096, b"\0")
+    payload = (np.arange(100000, dtype=np.uint32) % 251).astype(np.uint8).tobytes()
+
+    def feed():
+        with open(path, "wb", buffering=0) as f:
+            data = hdr + payload
+            for i in range(0, len(data), 3001):       # odd-sized pieces
+                f.write(data[i:i + 3001])
+
+    t = threading.Thread(target=feed, daemon=True)
+    t.start()
+    fr = dada.FileRing(path)
+    assert vdif.ascii_header_parse(fr.next_header()) == {"STATIONID": "7"}
+    a = fr.read(50000)
+    assert a == payload[:50000]
+    buf = np.zeros(40000, np.uint8)
+    assert fr.readinto(buf) == 40000 and buf.tobytes() == payload[50000:90000]
+    tail = fr.read(50000)
+    assert tail == payload[90000:]                    # short read at end of data
+    assert fr.read(10) == b""
+    t.join(timeout=10)
+    assert not t.is_alive()
+
+
 def test_genbase_recipe_small():
     assert genbase.dm_samples(30.0) == (1141760, 1526784) or sum(genbase.dm_samples(30.0)) > 2e6
     n_lo, n_hi = genbase.dm_samples(30.0)

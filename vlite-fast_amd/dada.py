@@ -11,7 +11,10 @@ programs against the small interface below; two implementations ship:
   MemoryRing   in-process (tests, and producer/consumer threads)
   FileRing     a file on disk: 4096-byte ASCII header followed by the frame stream -- the
                `readbase`-style replay of a recorded or generated dump
-               (/root/reference/src/readbase.c, src/genbase.cu:294 `-e`)
+               (/root/reference/src/readbase.c, src/genbase.cu:294 `-e`).  The path may also be a
+               FIFO: reads loop until the requested bytes have arrived, so a site with psrdada can
+               pipe a live ring in (and the FileSink outputs back out) through a few lines of C
+               around ipcio_read / ipcio_write -- INTEGRATION.md shows that bridge.
 
 `open_ring(key)` returns a PsrdadaRing when a `psrdada` Python binding is importable on the
 host (to be verified on a box that has psrdada), else raises.
@@ -108,17 +111,38 @@ class FileRing(ReadRing):
         if self._i >= len(self._paths):
             return None
         self._fp = open(self._paths[self._i], "rb", buffering=0)
-        hdr = self._fp.read(DADA_HDR_SIZE)
+        hdr = self.read(DADA_HDR_SIZE)
         if len(hdr) != DADA_HDR_SIZE:
             raise IOError("%s: short header" % self._paths[self._i])
         return hdr
 
     def read(self, nbytes):
-        return self._fp.read(nbytes)
+        """Up to nbytes; fewer only at end of data (a pipe may deliver a request in pieces)."""
+        first = self._fp.read(nbytes)
+        if first is None:
+            first = b""
+        if len(first) == nbytes or not first:
+            return first
+        parts, got = [first], len(first)
+        while got < nbytes:
+            more = self._fp.read(nbytes - got)
+            if not more:
+                break
+            parts.append(more)
+            got += len(more)
+        return b"".join(parts)
 
     def readinto(self, arr):
-        """Fill a uint8 numpy array (e.g. pinned staging) without an extra copy."""
-        return self._fp.readinto(memoryview(arr).cast("B"))
+        """Fill a uint8 numpy array (e.g. pinned staging) without an extra copy; returns the
+        number of bytes read (short only at end of data)."""
+        mv = memoryview(arr).cast("B")
+        got = 0
+        while got < len(mv):
+            n = self._fp.readinto(mv[got:])
+            if not n:
+                break
+            got += n
+        return got
 
     def finish_observation(self):
         pass
