@@ -1,6 +1,7 @@
 """Full-size segments (1024 rows x 12500 samples x 2 pols = 25.6 MB each, the reference's
-FFTS_PER_SEG) are too big for the scalar oracle, so parity at BASELINE's sizes is checked through
-size-independent properties of the path:
+FFTS_PER_SEG).  The C oracle takes about a second per such segment, so two of them are compared bit for
+bit (test_fullsize_two_segments_bit_exact_vs_oracle); at batch sizes beyond that, parity is checked
+through size-independent properties of the path:
   * batching invariance: S segments in one pb_process call == S calls of one segment (the bandpass is
     the only state carried, in order) == the same data in a different antenna slot of a batch;
   * the two FFT back ends (in-library LDS FFT vs hipFFT) agree to one quantiser step on < 0.2 % of the
@@ -31,6 +32,27 @@ def _submit(h, ant, x, n, nseg, seg0=0):
         base = x.data_ptr() + (seg0 + s) * 2 * n
         h.submit_planar_dev(ant, s, base, base + n, n)
     h.sync()
+
+
+def test_fullsize_two_segments_bit_exact_vs_oracle(oracle):
+    """Two consecutive full-size segments (bandpass carried) with RFI bursts, a row of weight 0, a
+    strongly flagged row and a dropped frame: both streams' codes and the bandpass state equal the
+    oracle's, at 8 and at 2 bits."""
+    from helpers import NCHAN, make_input, oracle_run
+    lp = libpb()
+    d = make_input(41, R, 2)
+    for nbit in (8, 2):
+        res, bp_raw, bp_kur = oracle_run(oracle, d, R, rfi_mode=2, npol=1, nbit=nbit)
+        with lp.PbHandle(nant=1, nbit=nbit, rows_per_seg=R, max_seg=2) as h:
+            for s in range(2):
+                h.submit_planar(0, s, d[s, 0], d[s, 1])
+            h.process(2)
+            out = h.fetch(0, 0, 2)
+            gr, gk = h.get_bandpass(0)
+        assert np.array_equal(out["raw"], np.concatenate([r.codes_raw for r in res]))
+        assert np.array_equal(out["kur"], np.concatenate([r.codes_kur for r in res]))
+        assert np.array_equal(gr.view(np.uint32), bp_raw.reshape(2, NCHAN)[:, 2155:].view(np.uint32))
+        assert np.array_equal(gk.view(np.uint32), bp_kur.reshape(2, NCHAN)[:, 2155:].view(np.uint32))
 
 
 def test_fullsize_batching_invariance():
