@@ -15,6 +15,7 @@ static hipError_t sync_all(pb_handle *h)
 {
     hipError_t e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess && h->s_det) e = hipStreamSynchronize(h->s_det);
+    if (e == hipSuccess && h->s_copy) e = hipStreamSynchronize(h->s_copy);
     if (e == hipSuccess && h->s_kur) e = hipStreamSynchronize(h->s_kur);
     if (e == hipSuccess && h->s_coadd) e = hipStreamSynchronize(h->s_coadd);
     return e;
@@ -186,6 +187,7 @@ static int create_impl(pb_handle *h)
         HIPCHK(h, hipStreamCreateWithPriority(&h->s_det, hipStreamNonBlocking, hi));
     }
     HIPCHK(h, hipStreamCreateWithFlags(&h->s_kur, hipStreamNonBlocking));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_fftdone, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_kur, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_alldone, hipEventDisableTiming));
@@ -328,6 +330,7 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
     h->processed = 0;
     h->cur_set = 0;
     h->s_det = nullptr;
+    h->s_copy = nullptr;
     h->s_kur = nullptr;
     h->ev_fftdone = h->ev_kur = h->ev_alldone = nullptr;
     h->last_set = -1;
@@ -353,6 +356,7 @@ extern "C" void pb_destroy(pb_handle *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->s_det) (void)hipStreamSynchronize(h->s_det);
+    if (h->s_copy) (void)hipStreamSynchronize(h->s_copy);
     for (auto &kv : h->plans) hipfftDestroy(kv.second);
     bool stored = false;
     for (auto &b : h->sets) {
@@ -383,6 +387,7 @@ extern "C" void pb_destroy(pb_handle *h)
     for (int i = 0; i < 2; ++i)
         if (h->ev_coadd[i]) (void)hipEventDestroy(h->ev_coadd[i]);
     if (h->s_det) (void)hipStreamDestroy(h->s_det);
+    if (h->s_copy) (void)hipStreamDestroy(h->s_copy);
     if (h->s_kur) { (void)hipStreamSynchronize(h->s_kur); (void)hipStreamDestroy(h->s_kur); }
     if (h->ev_fftdone) (void)hipEventDestroy(h->ev_fftdone);
     if (h->ev_kur) (void)hipEventDestroy(h->ev_kur);
@@ -765,14 +770,17 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
             t.stop();
         }
         if (e2 == hipSuccess) e2 = hipEventRecord(h->ev_chan, h->s_det);   // this set's kernels are done
+        // the copy-out has a stream of its own: behind detect on s_det it would hold up the next batch's
+        // detect whenever it is slow (many antennas, few copy workgroups)
+        if (e2 == hipSuccess) e2 = hipStreamWaitEvent(h->s_copy, h->ev_chan, 0);
         for (int a = 0; a < h->A && e2 == hipSuccess; ++a)
             for (int st = 0; st < 2 && e2 == hipSuccess; ++st) {
                 if (st == 0 ? h->cfg.rfi_mode == 1 : h->cfg.rfi_mode == 0) continue;
                 const size_t o = ((size_t)a * 2 + st) * h->S * h->trim;
-                e2 = launch_copy_out(h->h_codes + o, h->d_codes + o, (size_t)nseg * h->trim, h->s_det);
+                e2 = launch_copy_out(h->h_codes + o, h->d_codes + o, (size_t)nseg * h->trim, h->s_copy);
             }
-        if (e2 == hipSuccess) e2 = hipEventRecord(h->ev_det, h->s_det);
-        if (e2 == hipSuccess) e2 = hipEventRecord(h->ev_alldone, h->s_det);
+        if (e2 == hipSuccess) e2 = hipEventRecord(h->ev_det, h->s_copy);
+        if (e2 == hipSuccess) e2 = hipEventRecord(h->ev_alldone, h->s_copy);
         h->stream = s_main;
         HIPCHK(h, e2);
         h->processed = nseg;

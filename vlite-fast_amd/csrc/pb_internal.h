@@ -83,7 +83,8 @@ struct pb_handle {
     };
     std::vector<BufSet> sets;
     int cur_set;
-    hipStream_t s_det;     // D2H (copy) stream
+    hipStream_t s_det;     // detect of the previous batch (pipelined mode); copy-out in the single-set mode
+    hipStream_t s_copy;    // copy-out of the filterbank bytes in pipelined mode, so that it does not hold up the next detect
     hipStream_t s_kur;     // kurtosis of the next batch, beside detect of the previous one
     hipEvent_t ev_fftdone, ev_kur, ev_alldone;
     int last_set;          // buffer set of the previous pb_process (-1: none)
