@@ -159,13 +159,20 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
     f2 t3[3][9];
     // twiddle tables through buffer descriptors: the per-r row offset goes in the scalar offset, so
     // the loads need no 64-bit vector address arithmetic
-    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)tw2, 0, 625 * 8, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc((void *)tw3, 0, M_HALF * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)tw2, 0, 25 * 24 * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc((void *)tw3, 0, 625 * 10 * 8, 0x00020000);
     auto load_t2 = [&]() {
         if (tid < 250) {
 #pragma unroll
-            for (int r = 1; r < 25; ++r)
-                t2[r - 1] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs2, k * 8, r * 200, 0));
+            // table layout [k][r = 1..24]: a thread's 24 twiddles are 192 contiguous bytes, fetched two
+            // per 16-byte load (vector-memory instructions, not bytes, are what the channeliser is short
+            // of: 12 loads here instead of 24)
+            for (int r = 1; r < 25; r += 2) {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                const f4 q = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs2, k * 192, (r - 1) * 8, 0));
+                t2[r - 1] = mk2(q.x, q.y);
+                t2[r] = mk2(q.z, q.w);
+            }
         }
     };
     auto load_t3 = [&]() {
@@ -174,9 +181,13 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
             const int j = tid + 256 * i;
             if (j < 625) {
 #pragma unroll
-                for (int r = 1; r < 10; ++r)
-                    t3[i][r - 1] =
-                        __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs3, j * 8, r * 5000, 0));
+                // table layout [j][r = 1..9, one pad]: 80 contiguous bytes per butterfly, five 16-byte loads
+                for (int r = 1; r < 10; r += 2) {
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    const f4 q = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs3, j * 80, (r - 1) * 8, 0));
+                    t3[i][r - 1] = mk2(q.x, q.y);
+                    if (r < 9) t3[i][r] = mk2(q.z, q.w);
+                }
             }
         }
     };

@@ -95,20 +95,23 @@ static float2 cis_neg(double num, double den)
 
 static int build_fft_tables(pb_handle *h)
 {
-    std::vector<float2> tw2(625), tw3(6250), post(PB_NCHAN);
-    for (int r = 0; r < 25; ++r)
-        for (int k = 0; k < 25; ++k) tw2[r * 25 + k] = cis_neg((double)(r * k), 625.0);
-    for (int r = 0; r < 10; ++r)
-        for (int k = 0; k < 625; ++k) tw3[r * 625 + k] = cis_neg((double)(r * k), 6250.0);
+    std::vector<float2> tw2(600), tw3(6250), post(PB_NCHAN);
+    // per-thread contiguous layouts (fft_lds.h): tw2[k][r-1], r = 1..24; tw3[j][r-1], r = 1..9 (+ 1 pad)
+    for (int k = 0; k < 25; ++k)
+        for (int r = 1; r < 25; ++r) tw2[k * 24 + (r - 1)] = cis_neg((double)(r * k), 625.0);
+    for (int j = 0; j < 625; ++j) {
+        for (int r = 1; r < 10; ++r) tw3[j * 10 + (r - 1)] = cis_neg((double)(r * j), 6250.0);
+        tw3[j * 10 + 9] = make_float2(0.f, 0.f);
+    }
     for (int k = 0; k < PB_NCHAN; ++k) {
         const double a = 2.0 * M_PI * (double)k / (double)PB_NFFT;
         post[k] = make_float2((float)(-sin(a)), (float)(-cos(a)));
     }
     FftTables &t = h->ft;
-    HIPCHK(h, dmalloc(h, &t.tw2, 625));
+    HIPCHK(h, dmalloc(h, &t.tw2, 600));
     HIPCHK(h, dmalloc(h, &t.tw3, 6250));
     HIPCHK(h, dmalloc(h, &t.post, PB_NCHAN));
-    HIPCHK(h, hipMemcpy(t.tw2, tw2.data(), 625 * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(t.tw2, tw2.data(), 600 * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(t.tw3, tw3.data(), 6250 * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(t.post, post.data(), PB_NCHAN * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(h, &t.postc, (size_t)PB_NCHANOUT));

@@ -28,8 +28,8 @@ struct FrbParams {
 // twiddle tables of the LDS FFT (all float2, built on the host in double); the radix-5/25/10 twiddles
 // are compile-time literals (fft_consts.h)
 struct FftTables {
-    float2 *tw2;    // [25][25]  (r, k)
-    float2 *tw3;    // [10][625]
+    float2 *tw2;    // [25 k][24 r]   pass-2 twiddles exp(-2 pi i r k / 625), r = 1..24
+    float2 *tw3;    // [625 j][10]    pass-3 twiddles exp(-2 pi i r j / 6250), r = 1..9, one pad
     float2 *post;   // [6251]
     float2 *postc;  // [4096] = post[2155..6250], its own 16-byte aligned allocation
     float *taps;    // [4][12500] FIR taps (taps=4) or nullptr
