@@ -125,8 +125,8 @@ def _cpu_chunk(arg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--backend", choices=["lds", "hipfft"], default="lds")
     ap.add_argument("--rfi-mode", type=int, default=2)
     ap.add_argument("--nbit", type=int, default=8)

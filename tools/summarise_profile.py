@@ -20,7 +20,7 @@ def main():
     src = os.path.join(root, "gpurun_out", "prof_" + tag)
     dst = os.path.join(root, "profiles")
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
+    stats = max(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)   # newest run
     rows = list(csv.DictReader(open(stats)))
     keep = [r for r in rows if r["Name"].lstrip("void ").startswith("k_")]
     with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (rnd, tag)), "w", newline="") as f:
@@ -29,7 +29,7 @@ def main():
         w.writerows(keep)
     traffic = {}
     for what, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-        f = glob.glob(os.path.join(src, what, "*", "*counter_collection.csv"))[0]
+        f = max(glob.glob(os.path.join(src, what, "*", "*counter_collection.csv")), key=os.path.getmtime)
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == ctr and r["Kernel_Name"].lstrip("void ").startswith("k_"):
