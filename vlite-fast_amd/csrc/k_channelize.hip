@@ -1,5 +1,5 @@
 // Channeliser: 8-bit unpack + 12500-point real FFT + square-law detect of the 4096 output
-// channels, one workgroup per (row, pol, stream), everything between the raw bytes and the
+// channels, one workgroup per (row, pol), everything between the raw bytes and the
 // power spectrum staying in registers and LDS.
 //
 // Replaces, per FFT row:  convertarray (src/pb_kernels.cu:23-33), the copy/zero half of
