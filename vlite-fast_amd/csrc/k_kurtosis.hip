@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void k_kurtosis_row(
     __shared__ float s2[50], s4[50], sdag[50];
     __shared__ unsigned sflag[25];
     __shared__ float spow[50], skur[50], sfb[4];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: block indices stay in scalar registers
     const int grow = blockIdx.x;  // seg * R + row
     const int ant = blockIdx.y;
     const int seg = grow / R, row = grow % R;
