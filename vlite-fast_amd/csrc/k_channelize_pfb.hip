@@ -27,7 +27,7 @@ struct PfbArgs {
     const uint8_t *hvalid;   // [A][3] history slot holds data
     const float *wrow;       // [A][S*R]  (already the PFB weights)
     size_t wrow_ant_stride;
-    const float *fir;        // [4][12500]
+    const float2 *fir;       // [6250 n][4 taps] coefficient pairs of samples (2n, 2n+1) (FftTables::taps_n)
     float *Praw, *Pkur;
     size_t p_ant_stride;
     const float2 *tw2, *tw3, *postc;
@@ -114,9 +114,12 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
         // window coefficients of samples (2n, 2n+1), n = tid + 250 r, tap j: through a buffer descriptor
         // with the lane part (8 tid) in the vector offset and (j, r) in the scalar offset
         const __amdgpu_buffer_rsrc_t rsF =
-            __builtin_amdgcn_make_buffer_rsrc((void *)a.fir, 0, 4 * PB_NFFT * 4, 0x00020000);
-        auto coef = [&](int j, int r) __attribute__((always_inline)) {
-            return __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rsF, tid * 8, (j * PB_NFFT + 500 * r) * 4, 0));
+            __builtin_amdgcn_make_buffer_rsrc((void *)a.fir, 0, 6250 * 4 * 8, 0x00020000);
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        // the four taps of sample pair n are 32 contiguous bytes, and consecutive lanes take consecutive
+        // n: two coalesced 16-byte loads per block r (taps 0,1 and 2,3) instead of four 8-byte ones
+        auto coef2 = [&](int jj, int r) __attribute__((always_inline)) {
+            return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsF, tid * 32, (250 * r * 4 + jj) * 8, 0));
         };
         const unsigned m0 = kur ? mask[0] : 0u, m1 = kur ? mask[1] : 0u, m2 = kur ? mask[2] : 0u,
                        m3 = kur ? mask[3] : 0u;
@@ -133,10 +136,11 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
             const unsigned w0 = pick(m0, s0[n]), w1 = pick(m1, s1[n]), w2 = pick(m2, s2[n]), w3 = pick(m3, s3[n]);
             // sum_j taps[j] * x_j, products then left-to-right adds (the order of k_channelize_f32),
             // re and im side by side in packed instructions
-            f2 acc = coef(0, r) * cvt_pair_c(w0);
-            acc = acc + coef(1, r) * cvt_pair_c(w1);
-            acc = acc + coef(2, r) * cvt_pair_c(w2);
-            acc = acc + coef(3, r) * cvt_pair_c(w3);
+            const f4 c01 = coef2(0, r), c23 = coef2(2, r);
+            f2 acc = mk2(c01.x, c01.y) * cvt_pair_c(w0);
+            acc = acc + mk2(c01.z, c01.w) * cvt_pair_c(w1);
+            acc = acc + mk2(c23.x, c23.y) * cvt_pair_c(w2);
+            acc = acc + mk2(c23.z, c23.w) * cvt_pair_c(w3);
             v[r] = acc;
             // five blocks at a time: letting the scheduler hoist all 100 coefficient loads spills
             if (r % 5 == 4) __builtin_amdgcn_sched_barrier(0);
@@ -246,7 +250,7 @@ hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now)
     a.hvalid = h->d_hist_valid;
     a.wrow = h->d_wrow;
     a.wrow_ant_stride = (size_t)h->S * h->R;
-    a.fir = h->ft.taps;
+    a.fir = h->ft.taps_n;
     a.Praw = h->d_Praw;
     a.Pkur = h->d_Pkur;
     a.p_ant_stride = (size_t)h->S * 2 * h->R * PB_NCHANOUT;

@@ -135,6 +135,12 @@ static int build_fft_tables(pb_handle *h)
                 taps[(size_t)j * ns + k] = (float)(win[(size_t)j * ns + k] * norms[0] * (j ? norms[j] : 1.0));
         HIPCHK(h, dmalloc(h, &t.taps, taps.size()));
         HIPCHK(h, hipMemcpy(t.taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
+        std::vector<float2> tn((size_t)(ns / 2) * 4);
+        for (int n = 0; n < ns / 2; ++n)
+            for (int j = 0; j < 4; ++j)
+                tn[(size_t)n * 4 + j] = make_float2(taps[(size_t)j * ns + 2 * n], taps[(size_t)j * ns + 2 * n + 1]);
+        HIPCHK(h, dmalloc(h, &t.taps_n, tn.size()));
+        HIPCHK(h, hipMemcpy(t.taps_n, tn.data(), tn.size() * sizeof(float2), hipMemcpyHostToDevice));
     }
     return PB_OK;
 }
@@ -382,7 +388,7 @@ extern "C" void pb_destroy(pb_handle *h)
     }
     void *ptrs[] = {h->d_vdif, h->d_frame_idx, h->d_bp, h->d_frb_delays, h->d_hist_in, h->d_hist_flags,
                     h->d_hist_valid, h->d_tapE, h->ft.tw2,
-                    h->ft.tw3, h->ft.post, h->ft.postc, h->ft.taps};
+                    h->ft.tw3, h->ft.post, h->ft.postc, h->ft.taps, h->ft.taps_n};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->d_coadd_codes) (void)hipFree(h->d_coadd_codes);

@@ -33,6 +33,7 @@ struct FftTables {
     float2 *post;   // [6251]
     float2 *postc;  // [4096] = post[2155..6250], its own 16-byte aligned allocation
     float *taps;    // [4][12500] FIR taps (taps=4) or nullptr
+    float2 *taps_n; // the same interleaved for the PFB channeliser: [6250 n][4 taps] pairs (samples 2n, 2n+1)
 };
 
 struct pb_handle {
