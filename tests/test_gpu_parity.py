@@ -251,27 +251,32 @@ def test_antenna_batch_and_coadd(oracle, nsets, own_stream):
     assert np.array_equal(codes, exp)
 
 
-def test_pipelined_buffer_sets_match_serial(oracle):
-    """nsets=2: batches alternate between buffer sets; the bandpass state still advances in
-    process order, so the concatenated output equals the oracle's serial run."""
+@pytest.mark.parametrize("nsets,nb,lag", [(2, 3, 1), (3, 7, 2), (2, 6, 0)])
+def test_pipelined_buffer_sets_match_serial(oracle, nsets, nb, lag):
+    """Batches rotate through nsets buffer sets and are collected `lag` batches later (0: at once);
+    kurtosis, channeliser, detect and copy-out of neighbouring batches overlap on four streams, the
+    bandpass state still advances in process order, so the concatenated output equals the oracle's
+    serial run."""
     lp = libpb()
-    nseg, nb = 2, 3
+    nseg = 2
     data = make_input(31, R, nseg * nb)
     got_raw, got_kur = [], []
-    with lp.PbHandle(nbit=8, rows_per_seg=R, max_seg=nseg, nsets=2) as h:
+
+    def collect(h, b):
+        h.select_set(b % nsets)
+        got_raw.append(h.fetch_view(0, 0, nseg).copy())
+        got_kur.append(h.fetch_view(0, 1, nseg).copy())
+
+    with lp.PbHandle(nbit=8, rows_per_seg=R, max_seg=nseg, nsets=nsets) as h:
         for b in range(nb):
-            h.select_set(b % 2)
+            h.select_set(b % nsets)
             for s in range(nseg):
                 h.submit_planar(0, s, data[b * nseg + s, 0], data[b * nseg + s, 1])
             h.process(nseg)
-            if b >= 1:
-                h.select_set((b - 1) % 2)
-                got_raw.append(h.fetch_view(0, 0, nseg).copy())
-                got_kur.append(h.fetch_view(0, 1, nseg).copy())
-        h.select_set((nb - 1) % 2)
-        o = h.fetch(0, 0, nseg)
-        got_raw.append(o["raw"])
-        got_kur.append(o["kur"])
+            if b >= lag:
+                collect(h, b - lag)
+        for b in range(max(0, nb - lag), nb):
+            collect(h, b)
     res, _, _ = oracle_run(oracle, data, R)
     assert np.array_equal(np.concatenate(got_raw), np.concatenate([r.codes_raw for r in res]))
     assert np.array_equal(np.concatenate(got_kur), np.concatenate([r.codes_kur for r in res]))
