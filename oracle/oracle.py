@@ -46,13 +46,29 @@ def build():
     subprocess.run(["make", "-s", "-C", _HERE], check=True)
 
 
+_VARIANT = "strict"
+_LIBS = {}
+
+
+def set_variant(name):
+    """"strict" (default; the oracle the HIP path is held to, bit for bit) or "fmad" (a*b+c fused
+    where nvcc's default may fuse it -- sensitivity measurements only, pb_oracle.c header)."""
+    global _VARIANT, _LIB
+    if name not in ("strict", "fmad"):
+        raise ValueError(name)
+    _VARIANT = name
+    _LIB = _LIBS.get(name)
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        path = os.path.join(_HERE, "liboracle.so" if _VARIANT == "strict" else "liboracle_fmad.so")
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)
+        L.orc_is_fmad.restype = C.c_int
+        assert L.orc_is_fmad() == (1 if _VARIANT == "fmad" else 0)
         fp = C.POINTER(C.c_float)
         up = C.POINTER(C.c_uint8)
         L.orc_powf_third.restype = C.c_float
@@ -80,6 +96,7 @@ def lib():
         L.orc_segment.argtypes = [up, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, fp, C.c_int,
                                   up, up, fp, fp, fp, fp, fp, fp]
         _LIB = L
+        _LIBS[_VARIANT] = L
     return _LIB
 
 
