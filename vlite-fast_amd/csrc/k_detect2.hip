@@ -2,27 +2,38 @@
 // filterbank bytes out).  Same reference kernels as k_detect.hip
 //   detect_and_normalize2 / 3, pscrunch(_weights), tscrunch(_weights), sel_and_dig_*
 //   (src/pb_kernels.cu:393-735)
-// but split so that only what is truly serial in time runs serially:
+// but split so that only what is truly serial in time runs serially.  One 384-thread workgroup = 32
+// channels x 2 pols of one stream, chunks of T rows, one barrier per chunk step:
 //
-//   loader   (1 wave): streams the power plane into an LDS ring D2_DEPTH chunks ahead with
-//            global_load_lds_dwordx4 (LDS-DMA): the 67 MB per segment are latency-bound
-//            unless ~4 chunks per workgroup are in flight, and DMA costs no registers;
-//   phase A  (1 wave, lane = 32 channels x 2 pols of one stream): the running-bandpass
-//            recurrence  bp = s*p + (1-s)*bp  with the 11x clip of the excised stream -- a
-//            handful of instructions per row -- leaving the bp used by each row in LDS;
-//   phase B  (2 waves, lane = one channel x one group of 8 rows): everything that only needs
-//            (p, bp) of its own row -- the normalising division, pol scrunch in double, the
-//            weighted 8-row time scrunch and the 8/4/2-bit quantiser.
-// Phase B of chunk k-1 overlaps phase A of chunk k (double-buffered LDS, one barrier per
-// chunk).  The excised stream's power plane already carries pow/w (the channeliser divides
-// by the row weight, see k_channelize.hip; +inf for rows of weight 0), so neither a division
-// nor the row weight sits on the serial path.
-// Stream, npol and nbit are template parameters and every data-dependent choice is a select,
-// so each phase is straight-line code the scheduler can interleave across rows.
+//   loader (wave 4): streams the power plane into an LDS ring D2_DEPTH chunks ahead with
+//            global_load_lds_dwordx4 (LDS-DMA, no registers);
+//   A  (wave 0, lane = (pol, channel)): the running-bandpass recurrence  bp = s*p + (1-s)*bp  with the 11x
+//            clip of the excised stream, for chunk k; leaves bp after every row in LDS;
+//   B  (waves 1, 2, 3, 5; lane = (8-row group, channel), both pols): everything that only needs (p, bp) of
+//            its own row -- the clip test again (same operands -> same result), the normalising division,
+//            pol scrunch in double, the weighted 8-row time scrunch and the 8/4/2-bit quantiser.  A B wave
+//            takes chunk c into registers at step c+1 and spends TWO steps on it (rows 0-3 of its groups,
+//            then rows 4-7 and the quantiser) while the wave of the other parity takes chunk c+1.
+//
+// What the round-2 measurements (tools/ubench_valu.hip, profiles/r02_notes.md) say about such a
+// kernel, and what this version does about it:
+//   * a wave issues ONE instruction -- vector, scalar or s_nop alike -- per ~4.5 cycles whatever the
+//     dependences; an LDS store costs the issuing wave ~16 cycles (13 per row as ds_write_b128 of four
+//     rows), an LDS load ~9.  The recurrence wave is therefore bound by its instruction COUNT per row:
+//     the bp it exports goes out as one 16-byte store per four rows, the select's two wait states
+//     after v_cmp (gfx950) carry the next row's s*p, "clipped" is not exported at all (phase B
+//     repeats the comparison), and the chunk bookkeeping is adds and compares, not divisions.
+//   * phase B was as long as the recurrence per chunk (2 waves x ~2400 cycles per 32 rows); four waves
+//     in two-step turns halve its per-step instruction stream.
+// The excised stream's power plane already carries pow/w (the channeliser divides by the row weight,
+// see k_channelize.hip; +inf for rows of weight 0), so neither a division nor the row weight sits on
+// the serial path.  Stream, npol and nbit are template parameters and every data-dependent choice is a
+// select, so each phase is straight-line code.
 //
 // Exactness notes (all selects reproduce the reference's branches bit for bit):
 //   (double)w >= 0.2  <=>  w >= 0.2f   (0.2f is the smallest float above 0.2);
-//   0.5*(w+w) == w exactly; adding +0.0f to a sum that started at +0.0f is the identity.
+//   0.5*(w+w) == w exactly; adding +0.0f to a sum that started at +0.0f is the identity;
+//   rows of weight 0 arrive as +inf: inf > bp*11 keeps the bandpass (:474-476), phase B zeroes x from w.
 //
 // HBM traffic: the power planes (4 B per row x channel x pol x stream) once; outputs 1/64 of it.
 #include "pb_internal.h"
@@ -38,19 +49,28 @@ struct Detect2Args {
     float scale, oms, tscale;
 };
 
-#define D2_DEPTH 2                 // chunks of power loads in flight per workgroup: 4 slots x 8 KB + 16 KB
-                                   // = 48 KB of LDS, so that a detect workgroup fits beside two channeliser
-                                   // workgroups of the next batch (deeper rings measured no faster)
-#define D2_NSLOT (D2_DEPTH + 2)    // LDS ring slots (a slot is re-filled two barriers after its last reader)
+#ifndef D2_DEPTH
+#define D2_DEPTH 2                 // chunks of power loads in flight per workgroup
+#endif
+#define D2_NSLOT (D2_DEPTH + 2)    // LDS ring slots: B takes chunk k-1 into registers during step k, A reads k,
+                                   // k+1 .. k+D2_DEPTH landed / in flight  (4 x 8 KB + 16 KB of bp = 49 KB:
+                                   // a detect workgroup fits beside two channeliser workgroups of the next batch)
+#define D2_THREADS 384
+#define D2_WAVE_A 0
+#define D2_WAVE_L 4
+
+namespace {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt()
 {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__device__ __forceinline__ float readlane_f(float v, int l)
+// LDS operations of this wave done, then the workgroup barrier.  (Not __syncthreads(): its release fence
+// may also drain vmcnt, i.e. the loader's DMA that must stay in flight across steps.)
+__device__ __forceinline__ void step_barrier()
 {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 template <int NBIT> __device__ __forceinline__ unsigned quantise(float acc)
@@ -67,13 +87,150 @@ template <int NBIT> __device__ __forceinline__ unsigned quantise(float acc)
     }
 }
 
-template <int T, bool KUR, int NPOL, int NBIT>
-__device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[T][64], float (*s_u)[T][64],
-                                             float (*s_w)[T])
+// which phase-B wave (0..3) a wave is, or -1: digit = parity * 2 + half of the (group, channel) lane tasks
+__device__ __forceinline__ int b_index(int wave)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    return wave == 1 ? 0 : (wave == 2 ? 1 : (wave == 3 ? 2 : (wave == 5 ? 3 : -1)));
+}
+
+// What a phase-B lane holds of its chunk between the two steps it spends on it
+template <int NPOL> struct BState {
+    float p[2][8];         // power, per pol, the 8 rows of the group
+    float4 u[2][2];        // bp after each row, per pol, rows 0-3 / 4-7
+    float uprev[2];        // bp before row 0
+    float w[8];            // row weights (excised stream)
+    float acc[2], wt_sumf;
+    int wt_sum;
+    int trow, seg;
+};
+
+// rows 4 h .. 4 h + 3 of the group
+template <int NPOL, bool KUR>
+__device__ __forceinline__ void phase_b_rows(BState<NPOL> &s, int h)
+{
+    if (h == 0) {
+        s.acc[0] = s.acc[1] = 0.f;
+        s.wt_sumf = 0.f;
+        s.wt_sum = 0;
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        float x[2];
+        const float w = KUR ? (h ? s.w[4 + jj] : s.w[jj]) : 1.f;
+#pragma unroll
+        for (int pol = 0; pol < 2; ++pol) {
+            const float4 u4 = h ? s.u[pol][1] : s.u[pol][0];
+            const float ub4 = h ? s.u[pol][0].w : s.uprev[pol];          // bp before this quad's first row
+            const float un = jj == 0 ? u4.x : (jj == 1 ? u4.y : (jj == 2 ? u4.z : u4.w));     // bp after the row
+            const float ub = jj == 0 ? ub4 : (jj == 1 ? u4.x : (jj == 2 ? u4.y : u4.z));      // bp before the row
+            const float p = h ? s.p[pol][4 + jj] : s.p[pol][jj];
+            float v = p / un - 1.f;
+            if (KUR) {
+                v = p > ub * 11.f ? 10.f : v;          // the recurrence wave's own test (:490-491): clipped -> 10
+                v = w == 0.f ? 0.f : v;                // :474-476
+            }
+            x[pol] = v;
+        }
+        if (NPOL == 1) {
+            const float sum = x[0] + x[1];
+            const float y = (float)(M_SQRT1_2 * (double)sum);
+            if (!KUR) {
+                s.acc[0] += y;
+            } else {
+                const bool ok = w >= 0.2f;           // MIN_WEIGHT, both pols share the row weight
+                s.wt_sum += ok ? 1 : 0;
+                s.wt_sumf += ok ? w : 0.f;
+                const float prod = w * y;
+                s.acc[0] += ok ? prod : 0.f;
+            }
+        } else {
+            if (!KUR) {
+                s.acc[0] += x[0];
+                s.acc[1] += x[1];
+            } else {
+                const bool ok = !(w < 0.2f);
+                s.wt_sum += ok ? 1 : 0;
+                s.wt_sumf += ok ? w : 0.f;
+                const float pr0 = w * x[0], pr1 = w * x[1];
+                s.acc[0] += ok ? pr0 : 0.f;
+                s.acc[1] += ok ? pr1 : 0.f;
+            }
+        }
+    }
+}
+
+template <int NPOL, int NBIT, bool KUR>
+__device__ __forceinline__ void phase_b_finish(const Detect2Args &a, const BState<NPOL> &s, int lane, int cB, int ntime,
+                                               uint8_t *codes, float *ave)
+{
+    float acc0 = s.acc[0], acc1 = s.acc[1];
+    if (!KUR) {
+        acc0 *= a.tscale;
+        acc1 *= a.tscale;
+    } else {
+        const bool ok = (s.wt_sumf / PB_NSCRUNCH) >= 0.2f;
+        const float d = sqrtf((float)s.wt_sum);
+        const float q0 = acc0 / d, q1 = acc1 / d;
+        acc0 = ok ? q0 : 0.f;
+        acc1 = ok ? q1 : 0.f;
+    }
+    uint8_t *cseg = codes + (size_t)s.seg * a.trim;
+    float *aseg = ave ? ave + (size_t)s.seg * a.ave_per_seg : nullptr;
+    const int trow = s.trow;
+#pragma unroll
+    for (int pol = 0; pol < NPOL; ++pol) {
+        const float acc = pol ? acc1 : acc0;
+        const size_t n = (NPOL == 1) ? (size_t)trow * PB_NCHANOUT + cB : ((size_t)trow * 2 + pol) * PB_NCHANOUT + cB;
+        if (aseg) aseg[(NPOL == 1) ? n : ((size_t)pol * ntime + trow) * PB_NCHANOUT + cB] = acc;
+        const unsigned q = quantise<NBIT>(acc);
+        if (NBIT == 8) {
+            cseg[n] = (uint8_t)q;
+        } else if (NBIT == 4) {
+            const unsigned hi = __shfl_down(q, 1);
+            if (!(lane & 1)) cseg[n >> 1] = (uint8_t)(q | (hi << 4));
+        } else {
+            const unsigned q1 = __shfl_down(q, 1);
+            const unsigned q2 = __shfl_down(q, 2);
+            const unsigned q3 = __shfl_down(q, 3);
+            if (!(lane & 3)) cseg[n >> 2] = (uint8_t)(q | (q1 << 2) | (q2 << 4) | (q3 << 6));
+        }
+    }
+}
+
+// Position of one pipeline stage: chunk index and what is derived from it, advanced with adds and compares
+// (a scalar division or remainder costs the wave tens of issue slots per step)
+struct Cursor {
+    int c, slot, seg, rb;      // chunk, ring slot (c mod NSLOT), segment, chunk within the segment
+    __device__ __forceinline__ void init(int c0, int cps)
+    {
+        c = c0;
+        const int m = c0 >= 0 ? c0 : 0;        // stages start at or before chunk 0: only c >= 0 is ever used
+        slot = m % D2_NSLOT;
+        seg = m / cps;
+        rb = m % cps;
+    }
+    __device__ __forceinline__ void next(int cps)
+    {
+        if (c >= 0) {
+            slot = slot + 1 == D2_NSLOT ? 0 : slot + 1;
+            rb = rb + 1;
+            if (rb == cps) { rb = 0; seg = seg + 1; }
+        }
+        c = c + 1;
+    }
+};
+
+}  // namespace
+
+template <int T, bool KUR, int NPOL, int NBIT>
+__device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[T][64], float4 (*s_u)[T / 4][64],
+                                             float (*s_u0)[64], float (*s_w)[T])
+{
+    // the wave index in a scalar register: every role test is a scalar branch, the step loops run on scalar counters
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int cg = blockIdx.x;
     constexpr int stream = KUR ? 1 : 0;
+    constexpr int NQ = T / 4, NG = T / PB_NSCRUNCH;
     const int ant = blockIdx.z;
     const int R = a.R, cps = R / T, nchunk = a.nseg * cps;
     const int ntime = R / PB_NSCRUNCH;
@@ -81,210 +238,199 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
     const size_t pol_stride = (size_t)R * PB_NCHANOUT, seg_stride = 2 * pol_stride;
     const float *Pant = a.P[stream] + (size_t)ant * a.S * seg_stride;
     constexpr int LPC = T / 4;        // DMA instructions per chunk (4 rows of 64 floats each)
+    const int nstep = nchunk + 2;     // step k: loader k + D, A chunk k, B chunks k-1 (first half) and k-2 (second half)
+    const int bi = b_index(wave);
 
-    // ---- loader (wave 3): lane -> (row in group of 4, pol, 4 channels)
-    const int ld_row = lane >> 4, ld_pol = (lane >> 3) & 1, ld_c = cg * 32 + (lane & 7) * 4;
-    auto issue = [&](int kk) {
-        const int seg = kk / cps, row0 = (kk % cps) * T;
-        const float *src = Pant + (size_t)seg * seg_stride + (size_t)ld_pol * pol_stride +
-                           (size_t)(row0 + ld_row) * PB_NCHANOUT + ld_c;
+    if (wave == D2_WAVE_L) {
+        // ---- loader: lane -> (row in group of 4, pol, 4 channels)
+        const int ld_row = lane >> 4, ld_pol = (lane >> 3) & 1, ld_c = cg * 32 + (lane & 7) * 4;
+        const size_t loff = (size_t)ld_pol * pol_stride + (size_t)ld_row * PB_NCHANOUT + ld_c;
+        auto issue = [&](const Cursor &cu) {
+            const float *src = Pant + (size_t)cu.seg * seg_stride + (size_t)(cu.rb * T) * PB_NCHANOUT + loff;
 #pragma unroll
-        for (int i = 0; i < LPC; ++i)
-            __builtin_amdgcn_global_load_lds(
-                (const void __attribute__((address_space(1))) *)(src + (size_t)(4 * i) * PB_NCHANOUT),
-                (void __attribute__((address_space(3))) *)&s_p[kk % D2_NSLOT][4 * i][0], 16, 0, 0);
-    };
-    if (wave == 3) {
-        for (int kk = 0; kk < D2_DEPTH && kk < nchunk; ++kk) issue(kk);
-        if (nchunk > D2_DEPTH - 1) wait_vmcnt<(D2_DEPTH - 1) * LPC>();
+            for (int i = 0; i < LPC; ++i)
+                __builtin_amdgcn_global_load_lds(
+                    (const void __attribute__((address_space(1))) *)(src + (size_t)(4 * i) * PB_NCHANOUT),
+                    (void __attribute__((address_space(3))) *)&s_p[cu.slot][4 * i][0], 16, 0, 0);
+        };
+        Cursor cu;
+        cu.init(0, cps);
+        for (int kk = 0; kk < D2_DEPTH && kk < nchunk; ++kk) {
+            issue(cu);
+            cu.next(cps);
+        }
+        if (nchunk > D2_DEPTH - 1) wait_vmcnt<(D2_DEPTH - 1) * LPC>();     // chunk 0 has landed
         else wait_vmcnt<0>();
-    }
-
-    // ---- phase A state (wave 0)
-    const int polA = lane >> 5, cA = cg * 32 + (lane & 31);
-    const float *inA = Pant + (size_t)polA * pol_stride + cA;
-    float *bpp = a.bp + (((size_t)ant * 2 + stream) * 2 + polA) * PB_NCHANOUT + cA;
-    float bp = (wave == 0) ? *bpp : 0.f;
-    // row weights of the next chunk are requested one iteration ahead (rows of chunk k are the
-    // contiguous wrow[k*T .. k*T+T-1]); a load issued in the iteration that uses it would put a full
-    // memory latency on every chunk
-    float wv_next = (KUR && wave == 0 && lane < T && nchunk > 0) ? wrow[lane] : 1.f;
-
-    // ---- phase B state (waves 1, 2)
-    const int idxB = (wave - 1) * 64 + lane;      // group-in-chunk * 32 + channel
-    const int gB = idxB >> 5, chB = idxB & 31;
-    const bool activeB = (wave == 1 || wave == 2) && gB < T / PB_NSCRUNCH;
-    const int cB = cg * 32 + chB;
-    uint8_t *codes = a.codes + ((size_t)ant * 2 + stream) * a.S * a.trim;
-    float *ave = a.ave ? a.ave + ((size_t)ant * 2 + stream) * a.S * a.ave_per_seg : nullptr;
-    const float scale = a.scale, oms = a.oms, tscale = a.tscale;
-    __syncthreads();
-
-    for (int k = 0; k <= nchunk; ++k) {
-        const int buf = k & 1;
-        if (wave == 3) {
-            if (k + D2_DEPTH < nchunk) {
-                issue(k + D2_DEPTH);
-                wait_vmcnt<(D2_DEPTH - 1) * LPC>();   // chunk k+1 has landed
+        step_barrier();
+        for (int k = 0; k < nstep; ++k) {
+            if (cu.c < nchunk) {
+                issue(cu);                              // chunk k + D2_DEPTH
+                cu.next(cps);
+                wait_vmcnt<(D2_DEPTH - 1) * LPC>();     // chunk k + 1 has landed
             } else {
                 wait_vmcnt<0>();
             }
-        } else if (wave == 0 && k < nchunk) {
-            const int seg = k / cps, row0 = (k % cps) * T;
-            const int slot = k % D2_NSLOT;
-            const float *wseg = wrow + (size_t)seg * R;
-            const float wv = wv_next;
-            if (KUR) {
-                if (k + 1 < nchunk && lane < T) wv_next = wrow[(size_t)(k + 1) * T + lane];
-                if (lane < T) s_w[buf][lane] = wv;
-            }
-            if (row0 == 0 && bp == 0.f) {
-                // initialise the bandpass from this segment's mean (:406-411, :444-461)
-                const float *p = inA + (size_t)seg * seg_stride;
-                if (!KUR) {
-                    for (int t = 0; t < R; ++t) bp += p[(size_t)t * PB_NCHANOUT];
-                    bp /= (float)R;
-                } else {
-                    int good = 0;
-                    for (int t = 0; t < R; ++t) {
-                        if (wseg[t] == 0.f) continue;
-                        good++;
-                        bp += p[(size_t)t * PB_NCHANOUT];
-                    }
-                    if (good == 0) bp = 1.f;
-                    else bp /= (float)good;
-                }
-            }
-            float pk[T];
-#pragma unroll
-            for (int j = 0; j < T; ++j) pk[j] = s_p[slot][j][lane];
-#pragma unroll
-            for (int j = 0; j < T; ++j) {
-                float u;
-                const float t1 = scale * pk[j];
-                const float t2 = oms * bp;
-                const float bpn = t1 + t2;
-                if (!KUR) {
-                    bp = bpn;
-                    u = bp;
-                } else {
-                    // rows with weight 0 arrive as +inf from the channeliser, so the 11x clip test
-                    // alone keeps the bandpass unchanged for them (:474-476) as for clipped samples
-                    // (:493-494); phase B turns their x into 0 from the row weight
-                    const bool clip = pk[j] > bp * 11.f;
-                    bp = clip ? bp : bpn;
-                    u = clip ? -1.f : bp;
-                }
-                s_u[buf][j][lane] = u;
-            }
-        } else if (activeB && k >= 1) {
-            const int kb = k - 1, pb = kb & 1, slot = kb % D2_NSLOT;
-            const int seg = kb / cps, row0 = (kb % cps) * T;
-            float acc0 = 0.f, acc1 = 0.f, wt_sumf = 0.f;
-            int wt_sum = 0;
-            float p0[PB_NSCRUNCH], p1[PB_NSCRUNCH], u0[PB_NSCRUNCH], u1[PB_NSCRUNCH], wr[PB_NSCRUNCH];
-#pragma unroll
-            for (int j = 0; j < PB_NSCRUNCH; ++j) {
-                const int rl = gB * PB_NSCRUNCH + j;
-                p0[j] = s_p[slot][rl][chB];
-                p1[j] = s_p[slot][rl][32 + chB];
-                u0[j] = s_u[pb][rl][chB];
-                u1[j] = s_u[pb][rl][32 + chB];
-                wr[j] = KUR ? s_w[pb][rl] : 1.f;
-            }
-#pragma unroll
-            for (int j = 0; j < PB_NSCRUNCH; ++j) {
-                float x0 = p0[j] / u0[j] - 1.f;
-                float x1 = p1[j] / u1[j] - 1.f;
-                const float w = wr[j];
-                if (KUR) {
-                    x0 = u0[j] < 0.f ? 10.f : x0;
-                    x1 = u1[j] < 0.f ? 10.f : x1;
-                    x0 = w == 0.f ? 0.f : x0;
-                    x1 = w == 0.f ? 0.f : x1;
-                }
-                if (NPOL == 1) {
-                    const float s = x0 + x1;
-                    const float p = (float)(M_SQRT1_2 * (double)s);
-                    if (!KUR) {
-                        acc0 += p;
-                    } else {
-                        const bool ok = w >= 0.2f;           // MIN_WEIGHT, both pols share the row weight
-                        wt_sum += ok ? 1 : 0;
-                        wt_sumf += ok ? w : 0.f;
-                        const float prod = w * p;
-                        acc0 += ok ? prod : 0.f;
-                    }
-                } else {
-                    if (!KUR) {
-                        acc0 += x0;
-                        acc1 += x1;
-                    } else {
-                        const bool ok = !(w < 0.2f);
-                        wt_sum += ok ? 1 : 0;
-                        wt_sumf += ok ? w : 0.f;
-                        const float pr0 = w * x0, pr1 = w * x1;
-                        acc0 += ok ? pr0 : 0.f;
-                        acc1 += ok ? pr1 : 0.f;
-                    }
-                }
-            }
-            if (!KUR) {
-                acc0 *= tscale;
-                acc1 *= tscale;
-            } else {
-                const bool ok = (wt_sumf / PB_NSCRUNCH) >= 0.2f;
-                const float d = sqrtf((float)wt_sum);
-                const float q0 = acc0 / d, q1 = acc1 / d;
-                acc0 = ok ? q0 : 0.f;
-                acc1 = ok ? q1 : 0.f;
-            }
-            const int trow = (row0 >> 3) + gB;
-            uint8_t *cseg = codes + (size_t)seg * a.trim;
-            float *aseg = ave ? ave + (size_t)seg * a.ave_per_seg : nullptr;
-#pragma unroll
-            for (int pol = 0; pol < NPOL; ++pol) {
-                const float acc = pol ? acc1 : acc0;
-                const size_t n = (NPOL == 1) ? (size_t)trow * PB_NCHANOUT + cB
-                                             : ((size_t)trow * 2 + pol) * PB_NCHANOUT + cB;
-                if (aseg) aseg[(NPOL == 1) ? n : ((size_t)pol * ntime + trow) * PB_NCHANOUT + cB] = acc;
-                const unsigned q = quantise<NBIT>(acc);
-                if (NBIT == 8) {
-                    cseg[n] = (uint8_t)q;
-                } else if (NBIT == 4) {
-                    const unsigned hi = __shfl_down(q, 1);
-                    if (!(lane & 1)) cseg[n >> 1] = (uint8_t)(q | (hi << 4));
-                } else {
-                    const unsigned q1 = __shfl_down(q, 1);
-                    const unsigned q2 = __shfl_down(q, 2);
-                    const unsigned q3 = __shfl_down(q, 3);
-                    if (!(lane & 3)) cseg[n >> 2] = (uint8_t)(q | (q1 << 2) | (q2 << 4) | (q3 << 6));
-                }
-            }
+            step_barrier();
         }
-        __syncthreads();
+    } else if (wave == D2_WAVE_A) {
+        // ---- A: the recurrence.  lane -> (pol, channel)
+        __builtin_amdgcn_s_setprio(3);
+        const int polA = lane >> 5, cA = cg * 32 + (lane & 31);
+        const float *inA = Pant + (size_t)polA * pol_stride + cA;
+        float *bpp = a.bp + (((size_t)ant * 2 + stream) * 2 + polA) * PB_NCHANOUT + cA;
+        float bp = *bpp;
+        const float scale = a.scale, oms = a.oms;
+        // row weights of the next chunk are requested one step ahead (rows of chunk k are the contiguous
+        // wrow[k*T .. k*T+T-1]) and staged in LDS for phase B
+        float wv_next = (KUR && lane < T && nchunk > 0) ? wrow[lane] : 1.f;
+        Cursor cu;
+        cu.init(0, cps);
+        step_barrier();
+        for (int k = 0; k < nstep; ++k) {
+            if (k < nchunk) {
+                const int slot = cu.slot, buf = k & 1;
+                if (KUR) {
+                    const float wv = wv_next;
+                    if (k + 1 < nchunk && lane < T) wv_next = wrow[(size_t)(k + 1) * T + lane];
+                    if (lane < T) s_w[k % 3][lane] = wv;
+                }
+                if (cu.rb == 0 && bp == 0.f) {
+                    // initialise the bandpass from this segment's mean (:406-411, :444-461)
+                    const float *p = inA + (size_t)cu.seg * seg_stride;
+                    const float *wseg = wrow + (size_t)cu.seg * R;
+                    if (!KUR) {
+                        for (int t = 0; t < R; ++t) bp += p[(size_t)t * PB_NCHANOUT];
+                        bp /= (float)R;
+                    } else {
+                        int good = 0;
+                        for (int t = 0; t < R; ++t) {
+                            if (wseg[t] == 0.f) continue;
+                            good++;
+                            bp += p[(size_t)t * PB_NCHANOUT];
+                        }
+                        if (good == 0) bp = 1.f;
+                        else bp /= (float)good;
+                    }
+                }
+                float pk[T];
+#pragma unroll
+                for (int j = 0; j < T; ++j) pk[j] = s_p[slot][j][lane];
+                s_u0[buf][lane] = bp;
+                float t1 = scale * pk[0];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    float o[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int j = 4 * q + jj;
+                        const float pnext = pk[j + 1 < T ? j + 1 : j];
+                        float t2, t1n;
+                        if (!KUR) {
+                            // bp = s p + (1-s) bp (:419); the next row's s*p rides along
+                            asm volatile("v_mul_f32 %1, %4, %0\n\t"
+                                         "v_mul_f32 %2, %3, %6\n\t"
+                                         "v_add_f32 %0, %5, %1"
+                                         : "+v"(bp), "=&v"(t2), "=&v"(t1n)
+                                         : "v"(scale), "v"(oms), "v"(t1), "v"(pnext));
+                        } else {
+                            // t2 = (1-s) bp; lim = 11 bp; bpn = s p + t2; clip = p > lim (:490); bp = clip ? bp : bpn.
+                            // The select needs two wait states after the compare on gfx950: the next row's s*p
+                            // (the only independent work there is) and one s_nop.  28 cycles per row measured;
+                            // a v_cmpx that masks the add instead is slower (36: exec hazards).
+                            float lim;
+                            asm volatile("v_mul_f32 %1, %5, %0\n\t"
+                                         "v_mul_f32 %2, 0x41300000, %0\n\t"
+                                         "v_add_f32 %1, %7, %1\n\t"
+                                         "v_cmp_gt_f32 vcc, %6, %2\n\t"
+                                         "v_mul_f32 %3, %4, %8\n\t"
+                                         "s_nop 0\n\t"
+                                         "v_cndmask_b32 %0, %1, %0, vcc"
+                                         : "+v"(bp), "=&v"(t2), "=&v"(lim), "=&v"(t1n)
+                                         : "v"(scale), "v"(oms), "v"(pk[j]), "v"(t1), "v"(pnext)
+                                         : "vcc");
+                        }
+                        t1 = t1n;
+                        o[jj] = bp;
+                    }
+                    s_u[buf][q][lane] = make_float4(o[0], o[1], o[2], o[3]);
+                }
+                cu.next(cps);
+            }
+            step_barrier();
+        }
+        *bpp = bp;
+    } else if (bi >= 0) {
+        // ---- B.  wave -> (chunk parity, half of the lane tasks); lane task -> (8-row group, channel), both pols
+        const int par = bi >> 1, idxB = (bi & 1) * 64 + lane;
+        const int g = idxB >> 5, ch = idxB & 31;
+        const bool active = g < NG;
+        const int cB = cg * 32 + ch;
+        uint8_t *codes = a.codes + ((size_t)ant * 2 + stream) * a.S * a.trim;
+        float *ave = a.ave ? a.ave + ((size_t)ant * 2 + stream) * a.S * a.ave_per_seg : nullptr;
+        BState<NPOL> bs;
+        Cursor cu;                       // this wave's next chunk: those of its parity
+        cu.init(0, cps);
+        if (par) cu.next(cps);
+        step_barrier();
+        for (int k = 0; k < nstep; ++k) {
+            // step k: chunk k-1 was finished by A in step k-1.  If it is ours: take it into registers and do
+            // rows 0-3; otherwise finish the chunk taken in the previous step (rows 4-7, quantiser)
+            const int c1 = k - 1;
+            if (c1 >= 0 && (c1 & 1) == par) {
+                if (c1 < nchunk && active) {
+                    const int slot = cu.slot, ub = c1 & 1;
+#pragma unroll
+                    for (int pol = 0; pol < 2; ++pol) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) bs.p[pol][j] = s_p[slot][g * 8 + j][pol * 32 + ch];
+                        bs.u[pol][0] = s_u[ub][2 * g][pol * 32 + ch];
+                        bs.u[pol][1] = s_u[ub][2 * g + 1][pol * 32 + ch];
+                        // bp before the group's first row: the last row of the quad before it, or of the chunk before
+                        bs.uprev[pol] = g == 0 ? s_u0[ub][pol * 32 + ch] : s_u[ub][(g ? 2 * g : 1) - 1][pol * 32 + ch].w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bs.w[j] = KUR ? s_w[c1 % 3][g * 8 + j] : 1.f;
+                    bs.trow = cu.rb * NG + g;
+                    bs.seg = cu.seg;
+                    phase_b_rows<NPOL, KUR>(bs, 0);
+                }
+            } else if (c1 >= 1) {
+                if (c1 - 1 < nchunk && active) {
+                    phase_b_rows<NPOL, KUR>(bs, 1);
+                    phase_b_finish<NPOL, NBIT, KUR>(a, bs, lane, cB, ntime, codes, ave);
+                }
+                cu.next(cps);
+                cu.next(cps);
+            }
+            step_barrier();
+        }
+    } else {
+        step_barrier();
+        for (int k = 0; k < nstep; ++k) step_barrier();
     }
-    if (wave == 0) *bpp = bp;
 }
 
 // MODE = rfi_mode: 0 raw stream only, 1 excised only, 2 both (blockIdx.y picks the stream)
 template <int T, int NPOL, int NBIT, int MODE>
-__global__ __launch_bounds__(256) void k_detect2(Detect2Args a)
+__global__ __launch_bounds__(D2_THREADS) void k_detect2(Detect2Args a)
 {
     // ring of power chunks filled by LDS-DMA (global_load_lds_dwordx4: no registers, no VALU)
     __shared__ __attribute__((aligned(16))) float s_p[D2_NSLOT][T][64];
-    __shared__ float s_u[2][T][64];   // bp used for the row; < 0 marks a clipped sample
-    __shared__ float s_w[2][T];
-    if (MODE == 0 || (MODE == 2 && blockIdx.y == 0)) detect2_body<T, false, NPOL, NBIT>(a, s_p, s_u, s_w);
-    else detect2_body<T, true, NPOL, NBIT>(a, s_p, s_u, s_w);
+    // bp after each row, double-buffered per chunk: [row quad][column = (pol, channel)], four rows to a 16-byte
+    // entry; s_u0 = bp before the chunk's first row
+    __shared__ __attribute__((aligned(16))) float4 s_u[2][T / 4][64];
+    __shared__ float s_u0[2][64];
+    __shared__ float s_w[3][T];
+    if (MODE == 0 || (MODE == 2 && blockIdx.y == 0)) detect2_body<T, false, NPOL, NBIT>(a, s_p, s_u, s_u0, s_w);
+    else detect2_body<T, true, NPOL, NBIT>(a, s_p, s_u, s_u0, s_w);
 }
 
 template <int T, int NPOL, int NBIT>
 static void launch_mode(const Detect2Args &a, int mode, dim3 grid, hipStream_t st)
 {
-    if (mode == 0) k_detect2<T, NPOL, NBIT, 0><<<grid, 256, 0, st>>>(a);
-    else if (mode == 1) k_detect2<T, NPOL, NBIT, 1><<<grid, 256, 0, st>>>(a);
-    else k_detect2<T, NPOL, NBIT, 2><<<grid, 256, 0, st>>>(a);
+    if (mode == 0) k_detect2<T, NPOL, NBIT, 0><<<grid, D2_THREADS, 0, st>>>(a);
+    else if (mode == 1) k_detect2<T, NPOL, NBIT, 1><<<grid, D2_THREADS, 0, st>>>(a);
+    else k_detect2<T, NPOL, NBIT, 2><<<grid, D2_THREADS, 0, st>>>(a);
 }
 
 template <int T>
