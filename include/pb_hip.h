@@ -139,6 +139,15 @@ int pb_submit_planar_dev(pb_handle *h, int ant, int seg, const void *d_pol0, con
  * rows_per_seg-sized segments the block fills (10 per second at rows_per_seg = 1024).
  * Missing frames are zero-filled (the writer's gap fill, src/writer.c:674-688). */
 int pb_submit_vdif(pb_handle *h, int ant, int seg0, const uint8_t *block, size_t nbytes);
+/* The same with the block's time origin given explicitly (VDIF seconds-from-epoch of its first sample
+ * and the frame number within that second), as the reference places every frame by its own header
+ * (:1032-1045: frame number and thread id decide the slot, not arrival order): a frame that is absent --
+ * the very first one included -- leaves zeros, frames of other seconds in the block are ignored.
+ * pb_submit_vdif takes the origin from the block's first frame.  Both return as soon as the copies and
+ * the gather kernel are queued; `block` must stay untouched until the batch's output has been fetched
+ * (or pb_sync): page-locked memory makes the copy truly asynchronous. */
+int pb_submit_vdif_at(pb_handle *h, int ant, int seg0, const uint8_t *block, size_t nbytes,
+                      int64_t second, int64_t frame0);
 /* HBM-resident producers write here directly: [max_seg][2 pols][seg_samples_per_pol] u8 */
 int pb_input_dev(pb_handle *h, int ant, void **dptr, size_t *nbytes);
 

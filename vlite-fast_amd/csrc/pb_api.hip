@@ -326,6 +326,7 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
     h->d_in = h->d_vdif = h->d_flags = h->d_codes = nullptr;
     h->d_frame_idx = nullptr;
     h->vdif_cap = 0;
+    for (int i = 0; i < 8; ++i) { h->h_frame_idx[i] = nullptr; h->h_idx_cap[i] = 0; h->ev_idx[i] = nullptr; }
     h->d_wrow = h->d_stats = h->d_fraw = h->d_fkur = h->d_Praw = h->d_Pkur = h->d_bp = h->d_ave = nullptr;
     h->d_frb_delays = nullptr;
     h->d_hist_in = h->d_hist_flags = h->d_hist_valid = nullptr;
@@ -391,6 +392,10 @@ extern "C" void pb_destroy(pb_handle *h)
                     h->ft.tw3, h->ft.post, h->ft.postc, h->ft.taps, h->ft.taps_n};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (int i = 0; i < 8; ++i) {
+        if (h->h_frame_idx[i]) (void)hipHostFree(h->h_frame_idx[i]);
+        if (h->ev_idx[i]) (void)hipEventDestroy(h->ev_idx[i]);
+    }
     if (h->d_coadd_codes) (void)hipFree(h->d_coadd_codes);
     if (h->h_coadd_codes) (void)hipHostFree(h->h_coadd_codes);
     for (int i = 0; i < 2; ++i)
@@ -458,6 +463,12 @@ static hipError_t submit_stream(pb_handle *h, hipStream_t *out)
     if (h->sets.size() < 2) { *out = h->stream; return hipSuccess; }
     *out = h->s_kur;
     if (h->last_set == h->cur_set) return hipStreamWaitEvent(h->s_kur, h->ev_alldone, 0);
+    // hipFFT back end: its kurtosis pass (the last reader of d_in) runs on the MAIN stream, which s_kur is
+    // not ordered behind: staging batch k+2 into this set must wait for the latest FFT stage, which is
+    // queued behind every earlier reader of this set's input.  (LDS back end: kurtosis and the channeliser
+    // of this set ran two batches ago behind s_kur -> ev_kur -> main -> ev_fftdone -> s_kur of the batch
+    // between, so the order already holds and staging overlaps the running channeliser.)
+    if (h->cfg.fft_backend == PB_FFT_HIPFFT && h->last_set >= 0) return hipStreamWaitEvent(h->s_kur, h->ev_fftdone, 0);
     return hipSuccess;
 }
 
@@ -546,7 +557,8 @@ extern "C" int pb_submit_planar_dev(pb_handle *h, int ant, int seg, const void *
     return PB_OK;
 }
 
-extern "C" int pb_submit_vdif(pb_handle *h, int ant, int seg0, const uint8_t *block, size_t nbytes)
+extern "C" int pb_submit_vdif_at(pb_handle *h, int ant, int seg0, const uint8_t *block, size_t nbytes,
+                                 int64_t sec0, int64_t fr0)
 {
     if (!h || !block) return PB_EINVAL;
     if (check_ant(h, ant)) return PB_EINVAL;
@@ -556,12 +568,27 @@ extern "C" int pb_submit_vdif(pb_handle *h, int ant, int seg0, const uint8_t *bl
     const size_t nsegs = nfr * PB_VDIF_DATA / h->seg_samples;
     if (seg0 < 0 || seg0 + nsegs > (size_t)h->S) return fail(h, PB_EINVAL, "pb_submit_vdif: segments out of range");
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int set = h->cur_set;
+    // The frame index lives in page-locked memory of its own per buffer set, so that its H2D copy -- like
+    // the block's -- is asynchronous and this call returns without waiting for the device (it used to
+    // synchronise the stream because the index was a stack vector).  The event says the previous copy out
+    // of this buffer has completed.
+    if (h->h_idx_cap[set] < 2 * nfr) {
+        if (h->h_frame_idx[set]) {
+            HIPCHK(h, hipEventSynchronize(h->ev_idx[set]));
+            (void)hipHostFree(h->h_frame_idx[set]);
+            h->h_frame_idx[set] = nullptr;
+        }
+        HIPCHK(h, hipHostMalloc((void **)&h->h_frame_idx[set], 2 * nfr * sizeof(int32_t), hipHostMallocDefault));
+        h->h_idx_cap[set] = 2 * nfr;
+        if (!h->ev_idx[set]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_idx[set], hipEventDisableTiming));
+    } else {
+        HIPCHK(h, hipEventSynchronize(h->ev_idx[set]));
+    }
     // index the headers: word0 bits 0-29 seconds, word1 bits 0-23 frame, word3 bits 16-25 thread
-    std::vector<int32_t> idx(2 * nfr, -1);
+    int32_t *idx = h->h_frame_idx[set];
+    for (size_t i = 0; i < 2 * nfr; ++i) idx[i] = -1;
     uint32_t w0, w1, w3;
-    memcpy(&w0, block, 4);
-    memcpy(&w1, block + 4, 4);
-    const int64_t sec0 = w0 & 0x3fffffff, fr0 = w1 & 0xffffff;
     for (size_t i = 0; i < nslots; ++i) {
         const uint8_t *p = block + i * PB_VDIF_FRAME;
         memcpy(&w0, p, 4);
@@ -574,7 +601,7 @@ extern "C" int pb_submit_vdif(pb_handle *h, int ant, int seg0, const uint8_t *bl
         idx[(size_t)thread * nfr + rel] = (int32_t)i;
     }
     if (h->vdif_cap < nbytes) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, sync_all(h));
         if (h->d_vdif) { (void)hipFree(h->d_vdif); h->device_bytes -= h->vdif_cap; }
         if (h->d_frame_idx) (void)hipFree(h->d_frame_idx);
         h->d_vdif = nullptr;
@@ -583,11 +610,12 @@ extern "C" int pb_submit_vdif(pb_handle *h, int ant, int seg0, const uint8_t *bl
         HIPCHK(h, hipMalloc((void **)&h->d_frame_idx, 2 * nfr * sizeof(int32_t)));
         h->vdif_cap = nbytes;
     }
+    // d_vdif / d_frame_idx are shared by the buffer sets: every use of them is on the staging stream, in order
     hipStream_t ss;
     HIPCHK(h, submit_stream(h, &ss));
     HIPCHK(h, hipMemcpyAsync(h->d_vdif, block, nbytes, hipMemcpyHostToDevice, ss));
-    HIPCHK(h, hipMemcpyAsync(h->d_frame_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, ss));
-    HIPCHK(h, hipStreamSynchronize(ss));  // idx is a local
+    HIPCHK(h, hipMemcpyAsync(h->d_frame_idx, idx, 2 * nfr * sizeof(int32_t), hipMemcpyHostToDevice, ss));
+    HIPCHK(h, hipEventRecord(h->ev_idx[set], ss));
     {
         hipStream_t s_main = h->stream;
         h->stream = ss;
@@ -596,6 +624,15 @@ extern "C" int pb_submit_vdif(pb_handle *h, int ant, int seg0, const uint8_t *bl
         HIPCHK(h, e);
     }
     return PB_OK;
+}
+
+extern "C" int pb_submit_vdif(pb_handle *h, int ant, int seg0, const uint8_t *block, size_t nbytes)
+{
+    if (!h || !block || nbytes < PB_VDIF_FRAME) return PB_EINVAL;
+    uint32_t w0, w1;
+    memcpy(&w0, block, 4);
+    memcpy(&w1, block + 4, 4);
+    return pb_submit_vdif_at(h, ant, seg0, block, nbytes, (int64_t)(w0 & 0x3fffffff), (int64_t)(w1 & 0xffffff));
 }
 
 extern "C" int pb_input_dev(pb_handle *h, int ant, void **dptr, size_t *nbytes)

@@ -53,6 +53,9 @@ struct pb_handle {
     uint8_t *d_vdif;       // staging for one raw 1-s block
     int32_t *d_frame_idx;  // [2][frames] frame -> slot in block, -1 = missing
     size_t vdif_cap;
+    int32_t *h_frame_idx[8];   // page-locked frame index per buffer set (the H2D copy of it is asynchronous)
+    size_t h_idx_cap[8];
+    hipEvent_t ev_idx[8];      // that copy has completed: the host may rewrite the index
     uint8_t *d_flags;      // [A][S*R*25]
     float *d_wrow;         // [A][S*R]
     float *d_stats;        // debug: [A][3][2][S*R*25] pow,kur,dag

@@ -51,7 +51,7 @@ class PbTimers(C.Structure):
 
 EXPORTS = ["pb_config_default", "pb_create", "pb_destroy", "pb_last_error", "pb_query",
            "pb_set_stream", "pb_sync", "pb_reset_bandpass", "pb_reset_history", "pb_get_bandpass", "pb_set_bandpass",
-           "pb_submit_planar", "pb_submit_planar_dev", "pb_submit_vdif", "pb_input_dev", "pb_process", "pb_set_frb_params", "pb_select_set", "pb_fetch", "pb_fetch_ptr",
+           "pb_submit_planar", "pb_submit_planar_dev", "pb_submit_vdif", "pb_submit_vdif_at", "pb_input_dev", "pb_process", "pb_set_frb_params", "pb_select_set", "pb_fetch", "pb_fetch_ptr",
            "pb_output_dev", "pb_coadd_local", "pb_set_coadd_stream", "pb_coadd_finish", "pb_coadd_fetch_ptr", "pb_profile", "pb_get_timers",
            "pb_debug_fetch", "pb_channelize_f32", "pb_version", "pb_search_create", "pb_search_destroy",
            "pb_search_last_error", "pb_search_info", "pb_search_run"]
@@ -95,6 +95,7 @@ def load():
     L.pb_submit_planar.argtypes = [vp, C.c_int, C.c_int, u8p, u8p, C.c_size_t]
     L.pb_submit_planar_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_size_t]
     L.pb_submit_vdif.argtypes = [vp, C.c_int, C.c_int, u8p, C.c_size_t]
+    L.pb_submit_vdif_at.argtypes = [vp, C.c_int, C.c_int, u8p, C.c_size_t, C.c_int64, C.c_int64]
     L.pb_input_dev.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.pb_process.argtypes = [vp, C.c_int, C.c_int]
     L.pb_fetch.argtypes = [vp, C.c_int, C.c_int, C.c_int, u8p, u8p, fp, fp, fp]
@@ -207,9 +208,14 @@ class PbHandle(object):
         """d_pol0 / d_pol1: device addresses (e.g. torch tensor .data_ptr())."""
         self._chk(self._L.pb_submit_planar_dev(self._h, ant, seg, C.c_void_p(d_pol0), C.c_void_p(d_pol1), nsamp))
 
-    def submit_vdif(self, ant, seg0, block):
+    def submit_vdif(self, ant, seg0, block, second=None, frame0=0):
+        """Queue one block of VDIF frames (asynchronous: keep `block` untouched until the batch's output has
+        been fetched).  second / frame0: time origin of the block; default = its first frame's header."""
         block = np.ascontiguousarray(block, np.uint8)
-        self._chk(self._L.pb_submit_vdif(self._h, ant, seg0, _u8(block), block.size))
+        if second is None:
+            self._chk(self._L.pb_submit_vdif(self._h, ant, seg0, _u8(block), block.size))
+        else:
+            self._chk(self._L.pb_submit_vdif_at(self._h, ant, seg0, _u8(block), block.size, int(second), int(frame0)))
 
     def input_dev(self, ant):
         p, n = C.c_void_p(), C.c_size_t()
