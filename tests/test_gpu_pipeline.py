@@ -139,3 +139,54 @@ def test_gpu_vdif_gather_equals_host_demux():
         b = h2.fetch(0, 0, SEG)
     assert np.array_equal(a["raw"], b["raw"]) and np.array_equal(a["kur"], b["kur"])
     assert (ref == 0).sum() >= 5000
+
+
+def test_replay_with_dropped_frames_realigns(tmp_path, oracle):
+    """A frame lost in the middle of second 1 and the first frame of second 2 lost: the .fil files must equal
+    the oracle's over the same stream with exactly those frames zero-filled (the reference places every
+    frame by its own header and loses nothing else, src/process_baseband.cu:1017-1034)."""
+    nsec = 5
+    data = make_input(17, R, nsec * SEG, rfi=False, dropped=False)
+    hdr = vdif.writer_header(7, 0.8718, -0.72452, "B0833-45", 58000.0, "19A-331", 33, 3600)
+    dump = str(tmp_path / "obs.uw")
+    holes = {(1, 1, 57), (2, 0, 0)}                      # (second, thread, frame)
+    zeroed = data.copy().reshape(nsec, SEG, 2, R * 12500)
+    with open(dump, "wb") as f:
+        f.write(vdif.ascii_header_format(hdr))
+        for s in range(nsec):
+            p0 = np.concatenate([data[s * SEG + i, 0] for i in range(SEG)])
+            p1 = np.concatenate([data[s * SEG + i, 1] for i in range(SEG)])
+            blk = vdif.frame_block(p0, p1, 3600 + s, 33, 7).reshape(FPS, 2, 5032)
+            keep = np.ones((FPS, 2), bool)
+            for (hs, ht, hf) in holes:
+                if hs == s:
+                    keep[hf, ht] = False
+                    flat = zeroed[s, :, ht].reshape(-1)              # [SEG * R * 12500] of that pol (a copy)
+                    flat[hf * 5000:(hf + 1) * 5000] = 0
+                    zeroed[s, :, ht] = flat.reshape(SEG, R * 12500)
+            f.write(blk[keep].tobytes())
+    argv = ["-b", "8", "-w", "2", "-r", "2", "--replay", dump, "--datadir", str(tmp_path), "--logdir",
+            str(tmp_path / "logs"), "--no-control", "--rows-per-seg", str(R)]
+    assert pbmod.run(pbmod.build_parser().parse_args(argv)) == 0
+    nseg = (nsec - 1) * SEG
+    res, _, _ = oracle_run(oracle, zeroed.reshape(nsec * SEG, 2, R * 12500)[:nseg], R, rfi_mode=2, npol=1, nbit=8)
+    sp = sigproc.sigproc_header(7, 0.8718, -0.72452, "B0833-45", 57570 + 3600 / 86400., 1, 8)
+    assert (tmp_path / "20160701_010000_muos_ea07.fil").read_bytes() == sp + b"".join(r.codes_raw.tobytes() for r in res)
+    assert (tmp_path / "20160701_010000_muos_ea07_kur.fil").read_bytes() == sp + b"".join(r.codes_kur.tobytes() for r in res)
+
+
+def test_profile_pass_logs_the_stage_lines(tmp_path):
+    """-t: the per-stage PROFILE block of the reference (src/process_baseband.cu:1538-1556), with the fused
+    kernels under the labels of the stages they replace."""
+    nsec = 3
+    data = make_input(19, R, nsec * SEG, rfi=False, dropped=False)
+    dump = str(tmp_path / "obs.uw")
+    _dump(dump, data)
+    argv = ["-b", "8", "-w", "0", "-t", "--replay", dump, "--datadir", str(tmp_path), "--logdir", str(tmp_path / "logs"),
+            "--no-control", "--rows-per-seg", str(R)]
+    assert pbmod.run(pbmod.build_parser().parse_args(argv)) == 0
+    log = next((tmp_path / "logs").glob("*_process_*.log")).read_text()
+    for label in ("Proc Time...", "Read Time...", "Copy To Dev.", "Kurtosis....", "FFT.........", "Normalize...", "Write......."):
+        assert label in log
+    import re
+    assert float(re.search(r"FFT\.+([0-9.]+)", log).group(1)) > 0

@@ -200,3 +200,27 @@ def test_genbase_writes_replayable_dump(tmp_path):
     assert (h0["epoch"], h0["second"], h0["frame"], h0["thread"]) == (33, 3600, 0, 0)
     h_roll = vdif.unpack_header(data[400 * 5032:400 * 5032 + 32].tobytes())
     assert (h_roll["second"], h_roll["frame"]) == (3601, 0)
+
+
+def test_out_ring_header_all_keys_in_reference_order():
+    """write_psrdada_header (src/process_baseband.cu:136-201): seventeen keys, this order, these printf
+    formats (%d / %lf / %s / %lu), values from the incoming ring header and the first VDIF frame."""
+    inhdr = vdif.writer_header(7, 0.8718, -0.72452, "B0833-45", 58000.25, "19A-331", 33, 3600)
+    vh = vdif.unpack_header(vdif.pack_header(3600, 33, 0, 7, 0).tobytes())
+    t_unix = vdif.vdif_to_unixepoch(vh)
+    h = sigproc.psrdada_out_header(inhdr, vh, 1, 2, "/mnt/ssd/fildata/20160701_010000_muos_ea07_kur.fil", t_unix,
+                                   vdif.frame_mjd(vh), vdif.frame_mjd_sec(vh))
+    assert list(h.keys()) == ["STATIONID", "BEAM", "RA", "DEC", "NAME", "SCANSTART", "NCHAN", "BANDWIDTH", "CFREQ",
+                              "NPOL", "NBIT", "TSAMP", "UTC_START", "UNIXEPOCH", "VDIF_MJD", "VDIF_SEC", "SIGPROC_FILE"]
+    chbw = -64. / 6251
+    expect = {"STATIONID": "7", "BEAM": "7", "RA": "0.871800", "DEC": "-0.724520", "NAME": "B0833-45",
+              "SCANSTART": "58000.250000", "NCHAN": "4096", "BANDWIDTH": "%f" % (4096 * chbw),
+              "CFREQ": "%f" % (384. + 0.5 * (2155 + 6250 - 1) * chbw), "NPOL": "1", "NBIT": "2",
+              "TSAMP": "%f" % (12500. / 128000000 * 8 * 1e6), "UTC_START": "2016-07-01-01:00:00",
+              "UNIXEPOCH": "1467334800.000000", "VDIF_MJD": "57570", "VDIF_SEC": "3600",
+              "SIGPROC_FILE": "/mnt/ssd/fildata/20160701_010000_muos_ea07_kur.fil"}
+    assert h == expect
+    assert expect["TSAMP"] == "781.250000" and expect["BANDWIDTH"] == "-41.936330" and expect["CFREQ"] == "340.978403"
+    # on the ring it is a 4096-byte block of "KEY value" lines that parses back to the same pairs
+    raw = vdif.ascii_header_format(h)
+    assert len(raw) == 4096 and vdif.ascii_header_parse(raw) == expect

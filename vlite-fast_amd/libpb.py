@@ -170,7 +170,7 @@ class PbHandle(object):
         self.ave_per_seg = int(s.ave_floats_per_seg)
         self.rows = int(s.rows_per_seg)
         self.nblk = int(s.blocks_per_seg_pol)
-        self.nant, self.max_seg = nant, max_seg
+        self.nant, self.max_seg, self.nsets = nant, max_seg, nsets
 
     def _chk(self, rc):
         if rc != 0:

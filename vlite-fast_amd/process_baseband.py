@@ -155,7 +155,7 @@ def source_allowed(hdr):
     return any(i in hdr.get("DATAID", "") for i in ALLOW_IDS)
 
 
-def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None):
+def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None, control_sock=None):
     """Process observations until the input ring is exhausted or CMD_QUIT.  Returns the exit
     status of the reference (0, or 1 after a >1 s data skip)."""
     validate(args)
@@ -175,9 +175,10 @@ def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None):
     if handle is None:
         handle = lp.PbHandle(device=args.gpu_id, nant=1, nbit=args.nbit, npol=args.npol, rfi_mode=args.rfi_mode,
                              taps=args.taps, fft_backend=lp.FFT_LDS if args.fft_backend == "lds" else lp.FFT_HIPFFT,
-                             rows_per_seg=R, max_seg=SEG_PER_SEC, inject_frb=args.inject_frb)
+                             rows_per_seg=R, max_seg=SEG_PER_SEC, inject_frb=args.inject_frb, nsets=2)
     trim = handle.trim
-    ctl = None if args.no_control else open_control_socket()
+    nsets = handle.nsets
+    ctl = control_sock if control_sock is not None else (None if args.no_control else open_control_socket())
     blocks = None          # page-locked staging for one second of frames, allocated once
     tsamp = 12500.0 / 128e6 * 8
     exit_status, quit_ = 0, False
@@ -195,11 +196,12 @@ def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None):
         hdr = vdif.ascii_header_parse(raw_hdr)
         log("INFO", "Beginning new observation.")
         handle.reset_history(0)          # taps=4: the FIR window does not span observations
-        # One second of frames is assembled in page-locked memory (two buffers, alternating: the H2D of
-        # second k is known to be complete once its filterbank bytes have been fetched), read straight
-        # into place where the ring supports it -- one copy from the ring instead of three.
+        # One second of frames is assembled in page-locked memory (nsets + 1 buffers in turn: the H2D of
+        # second k is known to be complete once its filterbank bytes have been fetched, which happens
+        # before buffer k mod (nsets + 1) comes round again), read straight into place where the ring
+        # supports it -- one copy from the ring instead of three.
         if blocks is None:
-            blocks = [_pinned_bytes(sec_bytes), _pinned_bytes(sec_bytes)]
+            blocks = [_pinned_bytes(sec_bytes) for _ in range(nsets + 1)]
         readinto = getattr(in_ring, "readinto", None)
         first = in_ring.read(vdif.VD_FRM)
         if len(first) != vdif.VD_FRM:
@@ -249,45 +251,17 @@ def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None):
 
         current_sec = vh["second"]
         log("INFO", "Starting sec=%d, thread=%d" % (current_sec, vh["thread"]))
-        integrated_sec, fb_bytes = 0, 0
+        st = dict(integrated_sec=0, fb_bytes=0, t_rt=time.time())
         out_buf = []           # 10-s buffer of the stream heimdall gets (:691-697)
-        t_rt = time.time()
-        pending = first        # first frame of the second being assembled
-        while True:
-            # assemble one second: the pending frame + the rest of the block
-            block = blocks[integrated_sec % 2]
-            block[:vdif.VD_FRM] = np.frombuffer(pending, np.uint8)
-            if readinto is not None:
-                nrest = readinto(block[vdif.VD_FRM:]) or 0
-            else:
-                rest = in_ring.read(sec_bytes - vdif.VD_FRM)
-                nrest = len(rest)
-                if nrest == sec_bytes - vdif.VD_FRM:
-                    block[vdif.VD_FRM:] = np.frombuffer(rest, np.uint8)
-            if nrest != sec_bytes - vdif.VD_FRM:
-                if nrest % vdif.VD_FRM:
-                    log("INFO", "Packet size=%d, expected %d.  Aborting this observation."
-                        % (nrest % vdif.VD_FRM, vdif.VD_FRM))
-                break                                   # partial final second: dropped
-            # a second is dispatched only when a frame of the next second has arrived
-            nxt = in_ring.read(vdif.VD_FRM)
-            if len(nxt) != vdif.VD_FRM:
-                break                                   # end of data: the last second is dropped
-            nh = vdif.unpack_header(nxt)
-            if nh["second"] - current_sec > 1:
-                log("ERR", "Major data skip!  (%d vs. %d; thread = %d) Aborting this observation."
-                    % (nh["second"], current_sec, nh["thread"]))
-                exit_status, quit_ = 1, True
-                break
-            if test_for_cmd(ctl, CMD_QUIT):
-                log("INFO", "Received CMD_QUIT, indicating data taking is ceasing.  Exiting.")
-                quit_ = True
-                break
-            inject_now = 1 if (args.inject_frb and current_sec % 60 == 0) else 0
-            if inject_now:
-                log("INFO", "Injecting an FRB with integrated = %.2f!!!." % float(integrated_sec))
-            handle.submit_vdif(0, 0, block)
-            handle.process(SEG_PER_SEC, inject_now)
+        prof = dict(read=0.0, todev=0.0, write=0.0)
+        if args.profile_pass:
+            handle.timers(reset=True)
+            handle.profile(True)
+
+        def collect(k):
+            """filterbank bytes of queued second k -> files and rings (:1364-1441, :1482-1494)"""
+            t0 = time.time()
+            handle.select_set(k % nsets)
             out = handle.fetch(0, 0, SEG_PER_SEC, raw=args.rfi_mode != 1, kur=args.rfi_mode != 0)
             main_codes = out["raw"] if args.rfi_mode != 1 else out["kur"]
             heim_codes = out["kur"] if args.rfi_mode != 0 else out["raw"]
@@ -298,23 +272,107 @@ def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None):
                 fb_fp.write(main_codes[sl].tobytes())
                 if fb_kur_fp:
                     fb_kur_fp.write(out["kur"][sl].tobytes())
-                fb_bytes += trim
+                st["fb_bytes"] += trim
             out_buf.append(heim_codes.copy())
-            integrated_sec += 1
-            if integrated_sec % 10 == 0:
-                lag = (time.time() - t_rt) - 10.0 * (R / 1024.0)
+            st["integrated_sec"] += 1
+            if st["integrated_sec"] % 10 == 0:
+                lag = (time.time() - st["t_rt"]) - 10.0 * (R / 1024.0)
                 if lag > 0.5:
                     log("ERR", "Measured time exceeding integrated time: lag %.2f s" % lag)
-                t_rt = time.time()
-            if integrated_sec >= 10 and out_ring is not None:
-                if integrated_sec == 10:
+                st["t_rt"] = time.time()
+            if st["integrated_sec"] >= 10 and out_ring is not None:
+                if st["integrated_sec"] == 10:
                     out_ring.write(np.concatenate(out_buf))      # the full 10-s buffer
                 else:
                     out_ring.write(out_buf[-1])                  # then 1 s at a time
             if len(out_buf) > 10:
                 out_buf.pop(0)
+            prof["write"] += time.time() - t0
+
+        # Frames are placed by their own headers (thread id, frame number: :1017-1034), a second is
+        # closed by the first frame of another second (:1019, :1058) and dispatched only then -- so the last
+        # second of an observation is dropped -- and a frame that never arrives leaves zeros.  The frames of
+        # one second are gathered in a page-locked block in bulk; when frames were dropped the block
+        # swallows the head of the next second, which is carried over, so that the stream re-aligns at
+        # once (the reference loses the dropped frame and nothing else).
+        # Seconds are pipelined over the handle's buffer sets: second k is queued (H2D + kernels) before the
+        # output of second k-1 is collected, so the device works while the host reads and writes.
+        carry = bytes(first)   # frames of the second being assembled that have been read already
+        queued = 0             # seconds handed to the device
+        while True:
+            t0 = time.time()
+            block = blocks[queued % len(blocks)]
+            have = len(carry)
+            block[:have] = np.frombuffer(carry, np.uint8)
+            carry = b""
+            boundary = None    # bytes (>= one frame) of the next second, already read
+            eod = False
+            while boundary is None and not eod:
+                if have < sec_bytes:
+                    if readinto is not None:
+                        got = readinto(block[have:]) or 0
+                    else:
+                        rest = in_ring.read(sec_bytes - have)
+                        got = len(rest)
+                        block[have:have + got] = np.frombuffer(rest, np.uint8)
+                    if got % vdif.VD_FRM:
+                        log("INFO", "Packet size=%d, expected %d.  Aborting this observation."
+                            % (got % vdif.VD_FRM, vdif.VD_FRM))
+                        got -= got % vdif.VD_FRM
+                        eod = True
+                    elif got < sec_bytes - have:
+                        eod = True
+                    have += got
+                else:
+                    nxt = in_ring.read(vdif.VD_FRM)     # block full and all of this second: the next frame decides
+                    if len(nxt) != vdif.VD_FRM:
+                        if len(nxt):
+                            log("INFO", "Packet size=%d, expected %d.  Aborting this observation." % (len(nxt), vdif.VD_FRM))
+                        eod = True
+                        break
+                    if vdif.unpack_header(nxt)["second"] != current_sec:
+                        boundary = nxt
+                    continue                            # (a duplicate frame of this second: dropped)
+                secs = block[:have].reshape(-1, vdif.VD_FRM)[:, :4].copy().view("<u4")[:, 0] & 0x3FFFFFFF
+                other = np.nonzero(secs != current_sec)[0]
+                if other.size:
+                    cut = int(other[0]) * vdif.VD_FRM
+                    boundary = block[cut:have].tobytes()
+                    # what follows the cut is not this second's: hide it from the device-side frame index
+                    block[cut:have].reshape(-1, vdif.VD_FRM)[:, 3] |= 0x80      # VDIF invalid-data bit
+                    have = cut
+            prof["read"] += time.time() - t0
+            if boundary is None:
+                break                                   # end of data: the last (partial or whole) second is dropped
+            nh = vdif.unpack_header(boundary[:vdif.VD_FRM])
+            if nh["second"] - current_sec > 1:
+                log("ERR", "Major data skip!  (%d vs. %d; thread = %d) Aborting this observation."
+                    % (nh["second"], current_sec, nh["thread"]))
+                exit_status, quit_ = 1, True
+                break
+            if test_for_cmd(ctl, CMD_QUIT):
+                log("INFO", "Received CMD_QUIT, indicating data taking is ceasing.  Exiting.")
+                quit_ = True
+                break
+            if have < sec_bytes:
+                # frames were dropped: whatever an earlier second left in the tail of the block is not data
+                block[have:].reshape(-1, vdif.VD_FRM)[:, 3] |= 0x80
+            inject_now = 1 if (args.inject_frb and current_sec % 60 == 0) else 0
+            if inject_now:
+                log("INFO", "Injecting an FRB with integrated = %.2f!!!." % float(queued))
+            t0 = time.time()
+            handle.select_set(queued % nsets)
+            handle.submit_vdif(0, 0, block, second=current_sec, frame0=0)
+            handle.process(SEG_PER_SEC, inject_now)
+            prof["todev"] += time.time() - t0
+            queued += 1
+            if queued - st["integrated_sec"] >= nsets:
+                collect(st["integrated_sec"])           # the oldest queued second, while the newest computes
             current_sec = nh["second"]
-            pending = nxt
+            carry = boundary
+        while st["integrated_sec"] < queued:
+            collect(st["integrated_sec"])
+        integrated_sec, fb_bytes = st["integrated_sec"], st["fb_bytes"]
 
         if out_ring is not None:
             out_ring.end_of_data()
@@ -328,6 +386,19 @@ def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None):
         nsamp = fb_bytes * (8 // args.nbit) // 4096
         log("INFO", "Wrote %.2f MB (%.2f s) to %s" % (fb_bytes * 1e-6, nsamp * tsamp, fb))
         log("INFO", "Proc Time...%.3f" % (time.time() - t_obs))
+        if args.profile_pass:
+            # the reference's PROFILE block (:1538-1556).  Its kernels are fused here: "Convert" lives in the
+            # kurtosis and channeliser kernels, "FFT" is the channeliser (unpack + FFT + detect), and
+            # normalise / pscrunch / tscrunch / digitise are one kernel, reported under "Normalize".
+            handle.profile(False)
+            tm = handle.timers(reset=True)
+            ms = lambda k: tm.get(k, (0.0, 0))[0] * 1e-3
+            log("INFO", "Read Time...%.3f" % prof["read"])
+            log("INFO", "Copy To Dev.%.3f" % prof["todev"])
+            log("INFO", "Kurtosis....%.3f" % ms("kurtosis"))
+            log("INFO", "FFT.........%.3f" % (ms("channelize") + ms("fft") + ms("inject")))
+            log("INFO", "Normalize...%.3f" % ms("detect"))
+            log("INFO", "Write.......%.3f" % prof["write"])
         written_files.append((fb, fb_kur if args.rfi_mode == 2 else None))
         if args.profile_pass or args.single_pass:
             break

@@ -106,11 +106,12 @@ def frame_block(pol0, pol1, second, epoch, station, frame0=0, out=None):
     return out.reshape(-1)
 
 
-def deframe_block(block):
+def deframe_block(block, second=None, frame0=0):
     """Host-side restatement of the reference's demux loop (src/process_baseband.cu:1015-1067)
     for one block: returns uint8 [2][nframes*5000] placed by (thread, frame number) relative to
-    the first frame; missing frames stay zero.  The product path does this on the GPU
-    (pb_submit_vdif); this function serves tests and file tools."""
+    the block's time origin -- (second, frame0), or the first frame's header when second is None;
+    missing frames stay zero, frames outside the block's span are ignored.  The product path does
+    this on the GPU (pb_submit_vdif / pb_submit_vdif_at); this function serves tests and file tools."""
     block = np.asarray(block, np.uint8)
     nslots = block.size // VD_FRM
     fr = block[:nslots * VD_FRM].reshape(nslots, VD_FRM)
@@ -118,7 +119,8 @@ def deframe_block(block):
     sec = (w[:, 0] & 0x3FFFFFFF).astype(np.int64)
     num = (w[:, 1] & 0xFFFFFF).astype(np.int64)
     thr = (((w[:, 3] >> 16) & 0x3FF) != 0).astype(np.int64)
-    rel = (sec - sec[0]) * FRAMESPERSEC + num - num[0]
+    sec0, num0 = (sec[0], num[0]) if second is None else (second, frame0)
+    rel = (sec - sec0) * FRAMESPERSEC + num - num0
     nfr = nslots // 2
     out = np.zeros((2, nfr, VD_DAT), np.uint8)
     ok = (rel >= 0) & (rel < nfr) & ((w[:, 0] >> 31) == 0)
