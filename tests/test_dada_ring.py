@@ -1,0 +1,119 @@
+"""psrdada ring endpoints: vlite-fast_amd/dada.PsrdadaRing over the flat shim of
+include/pb_dada.h.  psrdada is absent here, so the class is driven against tests/mock_dada (the same
+symbols over in-memory rings: test infrastructure, not psrdada) -- what is under test is the binding, the
+call order and that `process_baseband -k/-K/-C` reaches the ring code and produces the reference's
+ring traffic: header + frames in; header, one write per segment (coadd ring); header, 10 s then 1 s
+(heimdall ring)."""
+import ctypes as C
+import importlib
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_host_loop import FPS, SEG, TRIM, FakeHandle, _args, _expected, _frames, _header
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dada = importlib.import_module("vlite-fast_amd.dada")
+vdif = importlib.import_module("vlite-fast_amd.vdif")
+pbmod = importlib.import_module("vlite-fast_amd.process_baseband")
+
+
+@pytest.fixture(scope="module")
+def mock():
+    src = os.path.join(ROOT, "tests", "mock_dada", "pb_dada_mock.c")
+    so = os.path.join(ROOT, "tests", "mock_dada", "libpb_dada_mock.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["gcc", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-o", so, src], check=True)
+    L = dada.bind_shim(C.CDLL(so))
+    L.pb_dada_mock_create.argtypes = [C.c_uint32]
+    L.pb_dada_mock_destroy.argtypes = [C.c_uint32]
+    L.pb_dada_mock_shutdown.argtypes = [C.c_uint32]
+    return L
+
+
+def _decls():
+    txt = open(os.path.join(ROOT, "include", "pb_dada.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pb_dada_[a-z_]+)\s*\(", txt)))
+
+
+def test_shim_and_mock_define_every_declared_symbol(mock):
+    names = _decls()
+    assert names == ["pb_dada_close", "pb_dada_end_read", "pb_dada_end_write", "pb_dada_next_header", "pb_dada_open",
+                     "pb_dada_read", "pb_dada_write", "pb_dada_write_header"]
+    shim = open(os.path.join(ROOT, "vlite-fast_amd", "csrc", "pb_dada_shim.c")).read()
+    for n in names:
+        assert hasattr(mock, n)
+        assert re.search(r"\b%s\s*\(pb_dada \*d|\b%s\s*\(uint32_t key" % (n, n), shim), n
+    # the shim is nothing but the reference's psrdada calls
+    for call in ("dada_hdu_create", "dada_hdu_set_key", "dada_hdu_connect", "dada_hdu_lock_read", "ipcbuf_get_next_read",
+                 "ipcbuf_mark_cleared", "ipcio_read", "dada_hdu_unlock_read", "dada_hdu_lock_write",
+                 "ipcbuf_get_next_write", "ipcbuf_mark_filled", "ipcio_write", "dada_hdu_unlock_write"):
+        assert call in shim
+
+
+def test_open_ring_without_the_shim_says_how_to_build_it(monkeypatch):
+    monkeypatch.setattr(dada, "SHIM_PATH", "/nonexistent/libpb_dada.so")
+    monkeypatch.setattr(dada, "_SHIM", None)
+    with pytest.raises(RuntimeError, match="make -C vlite-fast_amd/csrc dada"):
+        dada.open_ring(0x40)
+
+
+def test_ring_roundtrip_and_protocol(mock):
+    mock.pb_dada_mock_create(0x77)
+    try:
+        with pytest.raises(RuntimeError, match="key=78"):
+            dada.PsrdadaRing(0x78, "r", lib=mock)
+        w = dada.PsrdadaRing(0x77, "w", lib=mock)
+        with pytest.raises(IOError):
+            w.write(np.zeros(8, np.uint8))                      # data before a header
+        w.write_header(_header())
+        w.write(np.arange(10000, dtype=np.uint8))
+        w.end_of_data()
+        r = dada.PsrdadaRing(0x77, "r", lib=mock)
+        assert r.next_header() == bytes(_header())
+        assert r.read(6000) == (np.arange(6000) % 256).astype(np.uint8).tobytes()
+        buf = np.zeros(8000, np.uint8)
+        assert r.readinto(buf) == 4000 and np.array_equal(buf[:4000], (np.arange(6000, 10000) % 256).astype(np.uint8))
+        assert r.read(100) == b""                                # end of data
+        r.finish_observation()
+        mock.pb_dada_mock_shutdown(0x77)
+        assert r.next_header() is None                           # ring shut down
+        r.close()
+        w.close()
+    finally:
+        mock.pb_dada_mock_destroy(0x77)
+
+
+def test_process_baseband_on_ring_keys(mock, tmp_path, monkeypatch):
+    """`process_baseband -k 40 -K 42 -C 46` (scripts/start_process:50): all three endpoints are psrdada rings"""
+    for key in (0x40, 0x42, 0x46):
+        mock.pb_dada_mock_create(key)
+    monkeypatch.setattr(dada, "_SHIM", mock)
+    try:
+        fr = _frames(13)
+        feeder = dada.open_ring(0x40, "w")                       # stands in for writer (src/writer.c)
+        feeder.write_header(_header())
+        feeder.write(np.frombuffer(b"".join(f.tobytes() for f in fr), np.uint8))
+        feeder.end_of_data()
+        mock.pb_dada_mock_shutdown(0x40)
+        args = pbmod.build_parser().parse_args(
+            ["-k", "40", "-K", "42", "-C", "46", "-b", "8", "-w", "2", "-r", "2", "-g", "0", "-o", "--datadir", str(tmp_path),
+             "--logdir", str(tmp_path / "logs"), "--no-control", "--rows-per-seg", "8"])
+        assert args.key_in == 0x40 and args.key_out == 0x42 and args.key_co == 0x46
+        assert pbmod.run(args, handle=FakeHandle(nsets=2)) == 0
+        raw, kur = _expected(fr, 12)
+        co = dada.open_ring(0x46, "r")
+        ch = vdif.ascii_header_parse(co.next_header())
+        assert ch["NCHAN"] == "4096" and ch["SIGPROC_FILE"].endswith("_muos_ea99_kur.fil")
+        assert co.read(len(kur) + 1) == kur                      # every segment of the excised stream
+        out = dada.open_ring(0x42, "r")
+        oh = vdif.ascii_header_parse(out.next_header())
+        assert oh["SIGPROC_FILE"].endswith("_muos_ea07_kur.fil") and oh["NBIT"] == "8"
+        assert out.read(len(kur) + 1) == kur                     # 10 s in one write, then second 11 and 12
+    finally:
+        for key in (0x40, 0x42, 0x46):
+            mock.pb_dada_mock_destroy(key)

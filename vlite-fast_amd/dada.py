@@ -16,8 +16,9 @@ programs against the small interface below; two implementations ship:
                pipe a live ring in (and the FileSink outputs back out) through a few lines of C
                around ipcio_read / ipcio_write -- INTEGRATION.md shows that bridge.
 
-`open_ring(key)` returns a PsrdadaRing when a `psrdada` Python binding is importable on the
-host (to be verified on a box that has psrdada), else raises.
+  PsrdadaRing  the real thing: ctypes over a flat C shim (include/pb_dada.h, csrc/pb_dada_shim.c) around the
+               very psrdada calls the reference makes.  The shim is built where psrdada is installed;
+               `open_ring(key)` returns a PsrdadaRing when it is, else raises with the build line.
 """
 import os
 
@@ -178,12 +179,127 @@ def write_dump(path, header_raw, stream):
         f.write(bytes(memoryview(np.ascontiguousarray(stream)).cast("B")))
 
 
+class PsrdadaRing(ReadRing, WriteRing):
+    """A psrdada HDU through the flat C shim of include/pb_dada.h (vlite-fast_amd/csrc/pb_dada_shim.c,
+    built where psrdada is installed: `make -C vlite-fast_amd/csrc dada PSRDADA=<prefix>`).  The calls and
+    their order are the reference's (src/process_baseband.cu): connect :541-569; per observation
+    lock_read + blocking header read + mark_cleared :799-832, ipcio_read :838/:1034, unlock_read :1513;
+    lock_write + header + mark_filled(4096) :172-199, ipcio_write :1416-1422 / :1482-1494,
+    unlock_write :1498-1511."""
+
+    def __init__(self, key, mode="r", lib=None):
+        import ctypes as C
+        self._C = C
+        self._L = lib if lib is not None else load_shim()
+        self.key, self.mode = key, mode
+        err = C.create_string_buffer(256)
+        self._d = self._L.pb_dada_open(C.c_uint32(key), 0 if mode == "r" else 1, err, C.c_uint64(len(err)))
+        if not self._d:
+            raise RuntimeError(err.value.decode() or "Unable to connect to PSRDADA buffer key=%x!" % key)
+
+    # reader side
+    def next_header(self):
+        C = self._C
+        buf = C.create_string_buffer(DADA_HDR_SIZE)
+        n = self._L.pb_dada_next_header(self._d, buf)
+        if n < 0:
+            raise IOError("psrdada ring 0x%x: header read failed (%d)" % (self.key, n))
+        if n == 0:
+            return None                      # ring shut down (the reference then looks for CMD_QUIT, :810-823)
+        return buf.raw
+
+    def read(self, nbytes):
+        C = self._C
+        buf = C.create_string_buffer(nbytes)
+        n = self._L.pb_dada_read(self._d, buf, C.c_uint64(nbytes))
+        if n < 0:
+            raise IOError("psrdada ring 0x%x: Error on nread=%d." % (self.key, n))
+        return buf.raw[:n]
+
+    def readinto(self, arr):
+        """ipcio_read straight into a uint8 numpy array (page-locked staging): no intermediate copy"""
+        C = self._C
+        n = self._L.pb_dada_read(self._d, arr.ctypes.data_as(C.c_void_p), C.c_uint64(arr.size))
+        if n < 0:
+            raise IOError("psrdada ring 0x%x: Error on nread=%d." % (self.key, n))
+        return int(n)
+
+    def finish_observation(self):
+        if self._L.pb_dada_end_read(self._d) < 0:
+            raise IOError("psrdada ring 0x%x: dada_hdu_unlock_read failed" % self.key)
+
+    # writer side
+    def write_header(self, raw):
+        raw = bytes(raw)
+        if len(raw) != DADA_HDR_SIZE:
+            raise ValueError("psrdada header blocks are %d bytes" % DADA_HDR_SIZE)
+        if self._L.pb_dada_write_header(self._d, raw) < 0:
+            raise IOError("psrdada ring 0x%x: header write failed" % self.key)
+
+    def write(self, buf):
+        a = np.ascontiguousarray(buf)
+        n = self._L.pb_dada_write(self._d, a.ctypes.data_as(self._C.c_void_p), self._C.c_uint64(a.nbytes))
+        if n != a.nbytes:
+            raise IOError("psrdada ring 0x%x: ipcio_write wrote %d of %d bytes" % (self.key, n, a.nbytes))
+
+    def end_of_data(self):
+        if self._L.pb_dada_end_write(self._d) < 0:
+            raise IOError("psrdada ring 0x%x: dada_hdu_unlock_write failed" % self.key)
+
+    def close(self):
+        if getattr(self, "_d", None):
+            self._L.pb_dada_close(self._d)
+            self._d = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_SHIM = None
+SHIM_PATH = os.environ.get("PB_DADA_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpb_dada.so")
+
+
+def bind_shim(L):
+    """declare the prototypes of include/pb_dada.h on a loaded library"""
+    import ctypes as C
+    vp = C.c_void_p
+    L.pb_dada_open.restype = vp
+    L.pb_dada_open.argtypes = [C.c_uint32, C.c_int, C.c_char_p, C.c_uint64]
+    L.pb_dada_next_header.restype = C.c_int64
+    L.pb_dada_next_header.argtypes = [vp, C.c_char_p]
+    L.pb_dada_read.restype = C.c_int64
+    L.pb_dada_read.argtypes = [vp, vp, C.c_uint64]
+    L.pb_dada_end_read.argtypes = [vp]
+    L.pb_dada_write_header.argtypes = [vp, C.c_char_p]
+    L.pb_dada_write.restype = C.c_int64
+    L.pb_dada_write.argtypes = [vp, vp, C.c_uint64]
+    L.pb_dada_end_write.argtypes = [vp]
+    L.pb_dada_close.restype = None
+    L.pb_dada_close.argtypes = [vp]
+    return L
+
+
+def load_shim(path=None):
+    """dlopen the psrdada shim (libpb_dada.so).  It exists only where it was built against psrdada."""
+    global _SHIM
+    if path is None and _SHIM is not None:
+        return _SHIM
+    import ctypes as C
+    p = path or SHIM_PATH
+    if not os.path.exists(p):
+        raise RuntimeError("psrdada ring requested but %s is not built: on a host with psrdada run "
+                           "`make -C vlite-fast_amd/csrc dada PSRDADA=<psrdada prefix>` (or point PB_DADA_LIB at "
+                           "the shim); without psrdada use --replay FILE / --out-sink / --co-sink" % p)
+    L = bind_shim(C.CDLL(p))
+    if path is None:
+        _SHIM = L
+    return L
+
+
 def open_ring(key, mode="r"):
-    """psrdada ring by hexadecimal key (as -k/-K/-C pass it).  Needs a psrdada binding on the
-    host; there is none in this image, so this fails loudly rather than pretending."""
-    try:
-        import psrdada  # noqa: F401
-    except ImportError:
-        raise RuntimeError("psrdada ring 0x%x requested but no psrdada binding is importable on this "
-                           "host; use --replay FILE (FileRing) or run where psrdada is installed" % key)
-    raise NotImplementedError("PsrdadaRing: to be wired and verified on a host with psrdada (SURVEY 8f-1)")
+    """psrdada ring by key (as -k/-K/-C pass it, parsed as hexadecimal): a PsrdadaRing over the shim.
+    Fails loudly when the shim has not been built (this image has no psrdada to build it against)."""
+    return PsrdadaRing(key, mode)
