@@ -110,6 +110,6 @@ def find_candidates(snr, width_log2, dms, tsamp, threshold=6.0, dm_tol=0.1, samp
 
 
 def candidate_line(c):
-    """One heimdall-format text line (columns of src/candidate.py:8-18)."""
-    return "%.6f\t%d\t%.6f\t%d\t%d\t%.4f\t%d\t%d\t%d" % (c["snr"], c["peak_idx"], c["peak_time"], c["tfilt"],
-                                                        c["dmi"], c["dm"], c["ngiant"], c["i0"], c["i1"])
+    """One heimdall-format text line (columns of src/candidate.py:8-18); see candidates.py for the TCP leg."""
+    import importlib
+    return importlib.import_module((__package__ or "vlite-fast_amd") + ".candidates").candidate_line(c)
