@@ -7,12 +7,19 @@ Contract:  python bench.py --gpus N --steps K --warmup W
           (10 segments x 1024 FFT rows x 12500 samples x 2 pols = 256 MB of 8-bit voltages)
           through kurtosis flagging -> channeliser -> detect/scrunch/quantise, with the raw
           samples already resident in HBM and the filterbank bytes copied back to the host.
+          The same JSON line carries sub-records measured right after the headline run:
+            taps4   the same step with the 4-tap polyphase window (north_star's PFB);
+            ingest  the same step with every second arriving from page-locked host memory as VDIF
+                    frames through pb_submit_vdif (PCIe-inclusive; never `value`);
+            search  one heimdall-sized gulp of the downstream dedispersion + boxcar search.
   N > 1   launched one rank per GPU by torch.distributed.run; antennas shard one per GPU
-          (weak scaling) and the per-step incoherent sum of the excised fp32 planes is an
+          (weak scaling; BASELINE configs[3] is this sharding with 2 antennas per GPU:
+          --ant-per-gpu 2) and the per-step incoherent sum of the excised fp32 planes is an
           RCCL reduce to rank 0 over xGMI, which requantises the coadded second.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -26,6 +33,17 @@ sys.path.insert(0, ROOT)
 
 NFFT, NCHANOUT, ROWS = 12500, 4096, 1024
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def kernel_source_hash():
+    """Identifies the kernels a committed PMC profile was taken with: sha256 over the HIP sources."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "vlite-fast_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def synth_second(torch, dev, seed, seg_samples, nseg, rfi_frac=0.0):
@@ -49,68 +67,10 @@ def synth_second(torch, dev, seed, seg_samples, nseg, rfi_frac=0.0):
     return out
 
 
-def cpu_baseline(quick=False):
-    """Reported-only CPU baseline named by north_star: the NumPy channeliser of
-    analysis/baseband.py (restated in oracle/oracle.py, pinned to the reference by
-    tests/golden) on a bounded sample of the same workload, from framed VDIF bytes to the
-    6251-channel detected plane, on this host's cores."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import multiprocessing as mp
-    import oracle as O
-    nseg = 2 if quick else 5                      # 0.2 / 0.5 s of one antenna, both pols
-    rows = ROWS * nseg
-    rng = np.random.default_rng(42)
-    nfr = rows * NFFT // 5000
-    raw = np.zeros((2 * nfr, 5032), np.uint8)
-    raw[:, 32:] = np.clip(rng.normal(128.5, 16.9, size=(2 * nfr, 5000)), 0, 255).astype(np.uint8)
-    raw = raw.ravel()
-    t0 = time.perf_counter()
-    v = O.vdif_get_data(raw)                      # deframe + de-interleave + float32
-    for p in range(2):
-        O.filterbank(v[p], nfft=NFFT)
-    t1 = time.perf_counter()
-    ncores = os.cpu_count() or 1
-    nsamp = rows * NFFT                           # dual-pol samples
-    one = nsamp / (t1 - t0) / 1e6
-    # all cores: FFT rows are independent -> split them over a process pool
-    chunks = [(p, i) for p in range(2) for i in range(ncores)]
-    global _CPU_V
-    _CPU_V = v
-    t2 = time.perf_counter()
-    with mp.get_context("fork").Pool(min(ncores, 32)) as pool:
-        pool.map(_cpu_chunk, [(p, i, ncores) for (p, i) in chunks])
-    t3 = time.perf_counter()
-    allc = nsamp / (t3 - t2) / 1e6
-    return {"value": round(allc, 2), "unit": "Msamp/s", "cores": min(ncores, 32), "kind": "port",
-            "value_1core": round(one, 2), "x_realtime": round(allc / 128.0, 4),
-            "sample": "%.1f s of one antenna, dual-pol: VDIF deframe + NumPy |rfft(12500)|^2 "
-                      "(analysis/baseband.py:filterbank restated); 1 core and a %d-process pool"
-                      % (nseg / 10.0, min(ncores, 32))}
-
+# ---------------------------------------------------------------------------------------------
+# CPU baseline (reported only).  Runs BEFORE torch / HIP are touched: it forks a process pool.
 
 _CPU_V = None
-
-
-def measured_traffic(stage, args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (tools/profile_gpu.sh + tools/summarise_profile.py; FETCH_SIZE / WRITE_SIZE collected in separate
-    passes and corrected as MI355X_MICROARCH.md prescribes).  None when no summary matches this
-    configuration (counters cannot be collected from inside the timed run)."""
-    import glob
-    if (args.backend != "lds" or args.rfi_mode != 2 or args.seg_per_step != 10 or args.ant_per_gpu != 1
-            or args.rfi_frac or args.taps != 1):
-        return None
-    names = {"kurtosis": "k_kurtosis_row", "channelize": "k_channelize", "detect": "k_detect2"}
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
-        try:
-            d = json.load(open(f))
-        except Exception:
-            continue
-        for k, t in d.get("kernels", {}).items():
-            if k.startswith(names.get(stage, "?")):
-                best = int(t["hbm_bytes_per_launch"])
-    return best
 
 
 def _cpu_chunk(arg):
@@ -122,59 +82,131 @@ def _cpu_chunk(arg):
     return hi - lo
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--backend", choices=["lds", "hipfft"], default="lds")
-    ap.add_argument("--rfi-mode", type=int, default=2)
-    ap.add_argument("--nbit", type=int, default=8)
-    ap.add_argument("--seg-per-step", type=int, default=10)
-    ap.add_argument("--ant-per-gpu", type=int, default=1)
-    ap.add_argument("--rfi-frac", type=float, default=0.0,
-                    help="fraction of 500-sample blocks given an impulsive RFI burst (default: clean noise)")
-    ap.add_argument("--taps", type=int, default=1, help="1 = rectangular window (reference GPU path), 4 = PFB")
-    ap.add_argument("--nsets", type=int, default=2, help="buffer sets (1 = no batch pipelining)")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
-    import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    ndev = torch.cuda.device_count()
-    local = local % max(ndev, 1)          # (rehearsals may put several ranks on one card)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
-        else:
-            dist.init_process_group(args.dist_backend)          # gloo: CPU rehearsal of the N > 1 path
 
-    lp = importlib.import_module("vlite-fast_amd.libpb")
+def cpu_baseline():
+    """The NumPy channeliser north_star names (analysis/baseband.py:filterbank, restated in oracle/oracle.py
+    and pinned to the reference by tests/golden) on BASELINE config 0's input: 1 s of one antenna, dual-pol,
+    from framed VDIF bytes (deframe + de-interleave + float32) to the 6251-channel detected plane, on this
+    host's cores -- once on one core, once with the FFT rows split over every core this process may use."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import multiprocessing as mp
+    import oracle as O
+    rows = ROWS * 10
+    rng = np.random.default_rng(42)
+    nfr = rows * NFFT // 5000
+    raw = np.zeros((2 * nfr, 5032), np.uint8)
+    for i in range(0, 2 * nfr, 4096):       # bounded temporaries
+        j = min(i + 4096, 2 * nfr)
+        raw[i:j, 32:] = np.clip(rng.standard_normal((j - i, 5000), dtype=np.float32) * 16.9 + 128.5, 0, 255).astype(np.uint8)
+    raw = raw.ravel()
+    t0 = time.perf_counter()
+    v = O.vdif_get_data(raw)                      # deframe + de-interleave + float32
+    t1 = time.perf_counter()
+    for p in range(2):
+        O.filterbank(v[p], nfft=NFFT)
+    t2 = time.perf_counter()
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    nsamp = rows * NFFT                           # dual-pol samples
+    one = nsamp / (t2 - t0) / 1e6
+    global _CPU_V
+    _CPU_V = v
+    chunks = [(p, i, ncores) for p in range(2) for i in range(ncores)]
+    t3 = time.perf_counter()
+    with mp.get_context("fork").Pool(ncores) as pool:
+        pool.map(_cpu_chunk, chunks)
+    t4 = time.perf_counter()
+    allc = nsamp / ((t4 - t3) + (t1 - t0)) / 1e6   # the deframe pass is not parallelised
+    _CPU_V = None
+    return {"value": round(allc, 2), "unit": "Msamp/s", "cores": ncores, "kind": "port",
+            "value_1core": round(one, 2), "x_realtime": round(allc / 128.0, 4), "cpu_model": cpu_model(),
+            "sample": "BASELINE configs[0]: 1.0 s of one antenna, dual-pol, 51 200 VDIF frames: deframe + NumPy "
+                      "|rfft(12500)|^2 over 20 480 rows (analysis/baseband.py:filterbank restated); 1 core, and the "
+                      "rows split over a %d-process pool (cores this process may run on)" % ncores}
+
+
+def measured_traffic(stage, args, taps):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of THIS build
+    (tools/profile_gpu.sh + tools/summarise_profile.py; FETCH_SIZE / WRITE_SIZE collected in separate passes
+    and corrected as MI355X_MICROARCH.md prescribes).  None when no summary matches the configuration or
+    when the kernels have changed since the profile was taken (source hash recorded in the summary)."""
+    import glob
+    if (args.backend != "lds" or args.rfi_mode != 2 or args.seg_per_step != 10 or args.ant_per_gpu != 1
+            or args.rfi_frac or taps != 1):
+        return None
+    names = {"kurtosis": "k_kurtosis_row", "channelize": "k_channelize", "detect": "k_detect2"}
+    best = None
+    sha = kernel_source_hash()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("kernel_source_sha16") != sha:
+            continue
+        for k, t in d.get("kernels", {}).items():
+            if k.startswith(names.get(stage, "?")):
+                best = int(t["hbm_bytes_per_launch"])
+    return best
+
+
+def algorithmic_bytes(args, h, n, world, taps):
+    """compulsory HBM bytes per antenna-segment of each kernel"""
+    nstreams = 2 if args.rfi_mode == 2 else 1
+    pbytes = nstreams * 2 * ROWS * NCHANOUT * 4                # power planes per antenna-segment
+    alg = {
+        "kurtosis": 2 * n + h.nblk,
+        "channelize": 2 * n + pbytes,
+        "fft": nstreams * (2 * n * 4 + 2 * ROWS * 6251 * 8),
+        "detect": (pbytes if args.backend == "lds" else nstreams * 2 * ROWS * 6251 * 8)
+                  + nstreams * (h.trim + (h.ave_per_seg * 4 if world > 1 else 0)),
+    }
+    if args.backend == "hipfft":
+        alg["kurtosis"] = 2 * n + nstreams * 2 * n * 4
+    return alg
+
+
+def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmup, ingest=False):
+    """One timed run of `steps` steps.  ingest: every second arrives as VDIF frames from page-locked host
+    memory (pb_submit_vdif), otherwise the samples are resident in HBM."""
     S, A = args.seg_per_step, args.ant_per_gpu
     backend = lp.FFT_LDS if args.backend == "lds" else lp.FFT_HIPFFT
     NSETS = args.nsets   # 2 = double-buffered batches: the D2H of second k and the host's collection of it overlap
-                # the kernels of second k+1
+                         # the kernels of second k+1
     h = lp.PbHandle(device=local, nant=A, nbit=args.nbit, npol=1, rfi_mode=args.rfi_mode,
-                    fft_backend=backend, rows_per_seg=ROWS, max_seg=S, keep_ave=(world > 1), nsets=NSETS,
-                    taps=args.taps)
+                    fft_backend=backend, rows_per_seg=ROWS, max_seg=S, keep_ave=(world > 1), nsets=NSETS, taps=taps)
     n = h.seg_samples
+    blocks = None
     for a in range(A):
         sec = synth_second(torch, dev, 42 + rank * A + a, n, S, rfi_frac=args.rfi_frac)
         torch.cuda.synchronize()
-        for st in range(NSETS):           # the same synthetic second sits in both buffer sets
-            h.select_set(st)
-            for s in range(S):
-                h.submit_planar_dev(a, s, sec[s][0].data_ptr(), sec[s][1].data_ptr(), n)
-        h.sync()
+        if ingest:
+            # frame the second the way genbase / writer do and keep it in page-locked host memory
+            vdif = importlib.import_module("vlite-fast_amd.vdif")
+            p0 = torch.cat([sec[s][0] for s in range(S)]).cpu().numpy()
+            p1 = torch.cat([sec[s][1] for s in range(S)]).cpu().numpy()
+            nfr = p0.size // 5000
+            blocks = [torch.empty(2 * nfr * 5032, dtype=torch.uint8, pin_memory=True) for _ in range(NSETS + 1)]
+            vdif.frame_block(p0, p1, 3600, 33, 7, out=blocks[0].numpy())
+            for b in blocks[1:]:
+                b.copy_(blocks[0])
+        else:
+            for st in range(NSETS):           # the same synthetic second sits in both buffer sets
+                h.select_set(st)
+                for s in range(S):
+                    h.submit_planar_dev(a, s, sec[s][0].data_ptr(), sec[s][1].data_ptr(), n)
+            h.sync()
         del sec
     d_sum = torch.zeros(S * h.ave_per_seg, dtype=torch.float32, device=dev) if world > 1 else None
     nant_total = world * A
@@ -202,6 +234,8 @@ def main():
     def step():
         k = state["k"]
         h.select_set(k % NSETS)
+        if ingest:
+            h.submit_vdif(0, 0, blocks[k % len(blocks)].numpy(), second=3600, frame0=0)
         h.process(S)
         if world > 1:
             with torch.cuda.stream(ts):
@@ -227,7 +261,7 @@ def main():
             collect(kk)
         state["k"] = 0
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     drain()
     h.sync()
@@ -237,7 +271,7 @@ def main():
     h.timers(reset=True)
     h.profile(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     drain()
     h.sync()
@@ -251,58 +285,144 @@ def main():
         t = torch.tensor([dt], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-
+    res = None
     if rank == 0:
-        samples = float(nant_total) * S * n * args.steps          # dual-pol samples
+        samples = float(nant_total) * S * n * steps          # dual-pol samples
         msamp = samples / dt / 1e6
-        nstreams = 2 if args.rfi_mode == 2 else 1
-        pbytes = nstreams * 2 * ROWS * NCHANOUT * 4                # power planes per antenna-segment
-        alg = {  # algorithmic (compulsory) HBM bytes per antenna-segment of each kernel, DESIGN.md section 5
-            "kurtosis": 2 * n + h.nblk,
-            "channelize": 2 * n + pbytes,
-            "fft": nstreams * (2 * n * 4 + 2 * ROWS * 6251 * 8),
-            "detect": (pbytes if args.backend == "lds" else nstreams * 2 * ROWS * 6251 * 8)
-                      + nstreams * (h.trim + (h.ave_per_seg * 4 if world > 1 else 0)),
-        }
-        if args.backend == "hipfft":
-            alg["kurtosis"] = 2 * n + nstreams * 2 * n * 4
+        alg = algorithmic_bytes(args, h, n, world, taps)
         stages = {k: v for k, v in tm.items() if v[1] > 0 and k in alg}
         dom = max(stages, key=lambda k: stages[k][0])
         avg_ms = stages[dom][0] / stages[dom][1]
         per_launch = alg[dom] * S * A
         achieved = per_launch / (avg_ms * 1e-3) / 1e9
-        chain_bps = {2: 66.09, 1: 34.04, 0: 34.04}[args.rfi_mode]  # SURVEY.md 8(d) B per dual-pol sample
-        traffic = measured_traffic(dom, args)
+        res = {"msamp": msamp, "ms_per_step": dt / steps * 1e3, "nant_total": nant_total,
+               "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                            "traffic": measured_traffic(dom, args, taps), "avg_launch_ms": round(avg_ms, 4),
+                            "algorithmic_bytes_per_launch": per_launch},
+               "stage_ms_per_step": {k: round(v[0] / steps, 4) for k, v in tm.items() if v[1] > 0}}
+    h.close()
+    return res
+
+
+def search_record(lp):
+    """Downstream search (BASELINE config 5) on one heimdall-sized gulp, production flags of
+    scripts/start_heimdall_single_antenna:21: 30 720 samples x 4096 channels of 8-bit codes, DM 2-1000 in
+    steps of 2 (500 trial DMs), boxcars 2^0..2^6, zapped channel ranges; H2D of the codes and D2H of the
+    S/N planes included.  Real-time factor = new samples per gulp (gulp minus the largest delay) / time."""
+    search = importlib.import_module("vlite-fast_amd.search")
+    T = search.HEIMDALL_GULP
+    rng = np.random.default_rng(1)
+    codes = np.clip(rng.normal(127.5, 1 / 0.02957, (T, NCHANOUT)), 0, 255).astype(np.uint8)
+    with search.Searcher(max_samples=T, dm_step=2.0) as s:
+        s.run(codes)
+        n, t0 = 5, time.perf_counter()
+        for _ in range(n):
+            s.run(codes)
+        dt = (time.perf_counter() - t0) / n
+        tout = T - s.max_delay
+        return {"ms_per_gulp": round(dt * 1e3, 3), "new_seconds_per_gulp": round(tout * s.tsamp, 3),
+                "x_realtime": round(tout * s.tsamp / dt, 1), "ndm": int(s.ndm), "nboxcar": int(s.nbox),
+                "nsamps_gulp": T}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--backend", choices=["lds", "hipfft"], default="lds")
+    ap.add_argument("--rfi-mode", type=int, default=2)
+    ap.add_argument("--nbit", type=int, default=8)
+    ap.add_argument("--seg-per-step", type=int, default=10)
+    ap.add_argument("--ant-per-gpu", type=int, default=1)
+    ap.add_argument("--rfi-frac", type=float, default=0.0,
+                    help="fraction of 500-sample blocks given an impulsive RFI burst (default: clean noise)")
+    ap.add_argument("--taps", type=int, default=1, help="1 = rectangular window (reference GPU path), 4 = PFB")
+    ap.add_argument("--nsets", type=int, default=2, help="buffer sets (1 = no batch pipelining)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the taps4 / ingest / search sub-records")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # the CPU baseline forks a process pool: before torch / HIP are initialised in this process
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)          # (rehearsals may put several ranks on one card)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group(args.dist_backend)          # gloo: CPU rehearsal of the N > 1 path
+
+    lp = importlib.import_module("vlite-fast_amd.libpb")
+    S, A = args.seg_per_step, args.ant_per_gpu
+    r = run_chain(torch, dist, lp, args, dev, local, rank, world, args.taps, args.steps, args.warmup)
+
+    if rank == 0:
+        msamp, nant_total = r["msamp"], r["nant_total"]
+        which = ("configs[1]" if world == 1 and A == 1 else
+                 "configs[3] (16 antennas over 8 GPUs)" if world * A == 16 and world == 8 else
+                 "configs[3] sharding, %d antenna(s) per GPU" % A if world > 1 else "configs[2]-style batch")
         out = {
             "metric": "Msamp/s/antenna (dual-pol) and x real-time @128 MS/s; % HBM roofline",
             "value": round(msamp, 1), "unit": "Msamp/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "warmup": args.warmup, "ms_per_step": round(r["ms_per_step"], 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic genbase-style 8-bit Gaussian baseband (mean 128.5, sigma 16.9 codes), "
                     "%g%% of 500-sample blocks with impulsive RFI; resident in HBM" % (100 * args.rfi_frac),
-            "config": {"workload": "configs[1]: 1 antenna/GPU, 128 MS/s dual-pol, 1 s per step "
+            "config": {"workload": "%s: %d antenna/GPU, 128 MS/s dual-pol, 1 s per step "
                                    "(10 x 100-ms segments, 2048 x 12500-pt FFT rows each), RFI mode %d, "
-                                   "%d-bit out, taps=%d, %s FFT" % (args.rfi_mode, args.nbit, args.taps, args.backend),
+                                   "%d-bit out, taps=%d, %s FFT" % (which, A, args.rfi_mode, args.nbit, args.taps, args.backend),
                        "antennas": nant_total, "antennas_per_gpu": A, "segments_per_step": S,
                        "parallelism": "antenna-per-GPU" + ("+rccl-reduce-coadd" if world > 1 else "")},
             "msamp_per_antenna": round(msamp / nant_total, 1),
             "x_realtime_per_antenna": round(msamp / nant_total / 128.0, 1),
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
-                         "algorithmic_bytes_per_launch": per_launch},
-            "chain_model": {"bytes_per_sample": chain_bps,
-                            "equiv_GBps": round(msamp * 1e6 * chain_bps / 1e9, 1),
-                            "frac_of_peak": round(msamp * 1e6 * chain_bps / 1e9 / HBM_PEAK_GBS, 4),
-                            "note": "SURVEY.md 8(d) unfused-chain traffic model x measured samples/s"},
-            "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in tm.items() if v[1] > 0},
+            "roofline": r["roofline"],
+            "stage_ms_per_step": r["stage_ms_per_step"],
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_extras and args.taps == 1 and A == 1:
+            nsub = max(20, args.steps // 3)
+            t4 = run_chain(torch, dist, lp, args, dev, local, rank, world, 4, nsub, min(args.warmup, 5))
+            out["taps4"] = {"ms_per_step": round(t4["ms_per_step"], 4), "value": round(t4["msamp"], 1), "unit": "Msamp/s",
+                            "x_realtime_per_antenna": round(t4["msamp"] / 128.0, 1), "steps": nsub,
+                            "roofline": t4["roofline"], "stage_ms_per_step": t4["stage_ms_per_step"],
+                            "note": "4-tap Hamming WOLA window (analysis/baseband.py:1207-1237) in the streaming path"}
+            ing = run_chain(torch, dist, lp, args, dev, local, rank, world, 1, nsub, min(args.warmup, 5), ingest=True)
+            gbs = 2 * (S * ing_frames(S) * 5032) / (ing["ms_per_step"] * 1e-3) / 1e9
+            out["ingest"] = {"ms_per_step": round(ing["ms_per_step"], 4), "value": round(ing["msamp"], 1), "unit": "Msamp/s",
+                             "x_realtime_per_antenna": round(ing["msamp"] / 128.0, 1), "steps": nsub,
+                             "h2d_GBps": round(gbs, 1), "stage_ms_per_step": ing["stage_ms_per_step"],
+                             "note": "each second = 51 200 VDIF frames (257.6 MB) from page-locked host memory through "
+                                     "pb_submit_vdif (H2D + in-kernel deframe), pipelined over 2 buffer sets: "
+                                     "PCIe-bound; not the headline value"}
+            try:
+                out["search"] = search_record(lp)
+            except Exception as e:      # the search stage is not part of the headline path
+                out["search"] = {"error": str(e)}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
-    h.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def ing_frames(S):
+    """VDIF frames per thread per segment"""
+    return ROWS * NFFT // 5000
 
 
 if __name__ == "__main__":

@@ -53,7 +53,9 @@ def main():
         t["write_bytes_per_launch"] = t.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024
         t["hbm_bytes_per_launch"] = t["read_bytes_per_launch"] + t["write_bytes_per_launch"]
     bench = json.loads(open(os.path.join(src, "bench_stats.json")).read().strip().splitlines()[-1])
-    out = {"tag": tag, "bench_config": bench["config"], "bench_under_profiler": {k: bench[k] for k in ("value", "ms_per_step", "stage_ms_per_step")},
+    sys.path.insert(0, root)
+    import bench as benchmod
+    out = {"tag": tag, "kernel_source_sha16": benchmod.kernel_source_hash(), "bench_config": bench["config"], "bench_under_profiler": {k: bench[k] for k in ("value", "ms_per_step", "stage_ms_per_step")},
            "kernels": traffic,
            "note": "FETCH_SIZE / WRITE_SIZE in KiB, separate --pmc passes; read = FETCH_SIZE*1024*factor with the "
                    "gfx950 factor 2 where the access pattern calibrates to it (see read_factor_calibrated)"}
