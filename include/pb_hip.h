@@ -219,6 +219,16 @@ int pb_search_info(const pb_search *s, int *ndm, int *nbox, int *max_delay);
  * stats is [ndm][2] = clipped mean and rms of each dedispersed series */
 int pb_search_run(pb_search *s, const void *codes, int codes_on_device, int nsamp, int nbit, float *snr,
                   uint8_t *width_log2, uint32_t *series, float *stats, int *tout);
+/* Running baseline: the mean over `window_samples` samples around each sample is removed from every
+ * dedispersed series before it is normalised (heimdall smooths its baseline over 2 s); 0 (default) = one
+ * clipped mean per series. */
+int pb_search_set_baseline(pb_search *s, int window_samples);
+/* The same search returning only the points at or above `threshold`: peaks[4 i ..] = DM index, sample,
+ * S/N (float bits), log2 width, at most max_out of them; *npeaks = how many there were. */
+int pb_search_peaks(pb_search *s, const void *codes, int codes_on_device, int nsamp, int nbit, float threshold,
+                    int32_t *peaks, int max_out, int *npeaks, int *tout);
+/* device time of the last run's stages in ms: H2D, transpose, dedisperse, prefix + statistics, boxcar, D2H */
+int pb_search_timers(const pb_search *s, float *ms6);
 
 const char *pb_version(void);
 

@@ -101,3 +101,75 @@ def test_config5_full_band_candidates(oracle):
     toks = search.candidate_line(top).split()
     assert abs(float(toks[0]) - top["snr"]) < 1e-3 and int(toks[1]) == top["peak_idx"] and int(toks[4]) == top["dmi"]
     assert abs(float(toks[5]) - top["dm"]) < 1e-3 and int(toks[7]) <= top["peak_idx"] < int(toks[8]) and len(toks) == 9
+
+
+def test_peak_list_equals_thresholded_planes_and_bad_arguments():
+    nchan, T, tsamp = 256, 4096, search.TSAMP
+    fch1, foff = 361.94, -0.16
+    codes, _ = _plane(73, T, nchan, dm=40.0, t0=900, width=4, amp=0.8, fch1=fch1, foff=foff, tsamp=tsamp)
+    kw = dict(nchan=nchan, max_samples=T, fch1=fch1, foff=foff, tsamp=tsamp, dm_min=0.0, dm_max=80.0, dm_step=4.0,
+              boxcar_max=16, zap=())
+    with search.Searcher(**kw) as s:
+        r = s.run(codes)
+        pk = s.peaks(codes, 6.0)
+        tm = s.timers()
+        idm, it = np.nonzero(r["snr"] >= 6.0)
+        assert pk["total"] == idm.size > 0 and pk["tout"] == r["tout"]
+        got = sorted(zip(pk["dmi"].tolist(), pk["t"].tolist(), pk["snr"].tolist(), pk["width_log2"].tolist()))
+        ref = sorted(zip(idm.tolist(), it.tolist(), r["snr"][idm, it].tolist(), r["width_log2"][idm, it].tolist()))
+        assert got == ref
+        assert tm["dedisperse"] > 0 and set(tm) == {"h2d", "transpose", "dedisperse", "stats", "boxcar", "d2h"}
+        c1 = search.find_candidates(r["snr"], r["width_log2"], s.dms, s.tsamp, threshold=6.0)
+        c2 = search.candidates_from_peaks(pk, s.dms, s.tsamp)
+        assert c1[0] == c2[0]
+    lp = importlib.import_module("vlite-fast_amd.libpb")
+    with pytest.raises(lp.PbError, match="dm_min"):
+        search.Searcher(**dict(kw, dm_min=-4.0))
+
+
+def test_gulps_with_overlap_find_a_pulse_across_the_boundary():
+    """heimdall-style gulps: each searched with the max_delay samples before it.  A pulse whose sweep
+    straddles the gulp boundary is found once, at its stream position, like in a single-block search."""
+    nchan, T, tsamp = 512, 6144, search.TSAMP
+    fch1, foff = 361.94, -0.08
+    dm, t0 = 60.0, 1990
+    codes, delay = _plane(74, T, nchan, dm=dm, t0=t0, width=4, amp=0.8, fch1=fch1, foff=foff, tsamp=tsamp)
+    kw = dict(nchan=nchan, max_samples=4096, fch1=fch1, foff=foff, tsamp=tsamp, dm_min=0.0, dm_max=80.0, dm_step=4.0,
+              boxcar_max=16, zap=())
+    with search.Searcher(**dict(kw, max_samples=T)) as s:
+        whole = search.candidates_from_peaks(s.peaks(codes, 7.0), s.dms, s.tsamp)
+        maxd = s.max_delay
+    assert delay.max() > 100 and t0 < 2048 < t0 + delay.max()              # the sweep crosses sample 2048
+    with search.Searcher(**kw) as s:
+        g = search.GulpSearch(s, threshold=7.0)
+        found = []
+        for i in range(0, T, 2048):
+            found += g.push(codes[i:i + 2048])
+        assert g.done == T - maxd                                           # every output sample exactly once
+    top_w, top_g = whole[0], max(found, key=lambda c: c["snr"])
+    assert abs(top_w["dm"] - dm) <= 4 and abs(top_w["peak_idx"] - t0) <= 4
+    assert (top_g["dmi"], top_g["peak_idx"], top_g["tfilt"]) == (top_w["dmi"], top_w["peak_idx"], top_w["tfilt"])
+    assert abs(top_g["snr"] / top_w["snr"] - 1) < 0.1                       # (statistics are per gulp)
+    assert sum(1 for c in found if c["snr"] > 0.6 * top_g["snr"]) == 1     # once
+
+
+def test_running_baseline_follows_a_drifting_level():
+    nchan, T, tsamp = 256, 8192, search.TSAMP
+    fch1, foff = 361.94, -0.16
+    codes, _ = _plane(75, T, nchan, dm=40.0, t0=3000, width=4, amp=0.8, fch1=fch1, foff=foff, tsamp=tsamp)
+    drift = (12.0 * np.sin(2 * np.pi * np.arange(T) / 4000.0))[:, None]    # +-12 codes, slow against 2 s
+    drifted = np.clip(codes.astype(np.float64) + drift, 0, 255).astype(np.uint8)
+    kw = dict(nchan=nchan, max_samples=T, fch1=fch1, foff=foff, tsamp=tsamp, dm_min=0.0, dm_max=80.0, dm_step=4.0,
+              boxcar_max=16, zap=())
+    with search.Searcher(**kw) as s:
+        flat = search.candidates_from_peaks(s.peaks(codes, 6.0), s.dms, s.tsamp)[0]
+        glob = s.peaks(drifted, 6.0)
+        s.set_baseline(512)
+        run = search.candidates_from_peaks(s.peaks(drifted, 6.0), s.dms, s.tsamp)
+        run_flat = search.candidates_from_peaks(s.peaks(codes, 6.0), s.dms, s.tsamp)[0]
+    assert abs(run[0]["peak_idx"] - 3000) <= 4 and abs(run[0]["dm"] - 40) <= 4
+    assert run[0]["snr"] > 0.85 * flat["snr"]                     # the drift is gone from the normalisation
+    assert abs(run_flat["snr"] / flat["snr"] - 1) < 0.1           # and flat data are not harmed
+    # with one global mean per series the drift either buries the pulse or floods the list with false points
+    g0 = search.candidates_from_peaks(glob, np.arange(21) * 4.0, tsamp)
+    assert (not g0) or g0[0]["snr"] < 0.8 * flat["snr"] or glob["total"] > 20 * max(1, len(run))

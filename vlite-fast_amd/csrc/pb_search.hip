@@ -26,11 +26,18 @@ struct pb_search {
     float fch1, foff, tsamp, dm_min, dm_step;
     int max_delay;
     uint8_t *d_codes, *d_xt;       // raw block; channel-major [nchan][tpitch]
-    int32_t *d_delay;              // [ndm][nchan], -1 = zapped
+    int32_t *d_delay;              // [ndm][nchan], INT32_MIN = zapped channel
     uint32_t *d_D;                 // [ndm][max_samples]
     float *d_stats;                // [ndm][2] mean, rms
     float *d_snr;                  // [ndm][max_samples]
     uint8_t *d_wid;                // [ndm][max_samples] log2 width
+    uint64_t *d_P;                 // [ndm][tpitch + 1] prefix sums of D (P[0] = 0)
+    int32_t *d_peaks;              // [1 + 4 * max_peaks]: count, then (dm index, sample, S/N bits, log2 width)
+    int max_peaks;
+    int baseline;                  // running-baseline window in samples (0: one clipped mean per DM series)
+    int last_tout;
+    float ms[6];                   // last run: H2D, transpose, dedisperse, prefix + statistics, boxcar, D2H
+    hipEvent_t ev[7];
     size_t tpitch;
     hipStream_t stream;
     std::string err;
@@ -72,21 +79,82 @@ __global__ __launch_bounds__(256) void k_transpose_codes(const uint8_t *__restri
     }
 }
 
+// Brute-force dedispersion, tiled over (time, DM): one workgroup = 2048 output samples x DDM_DB
+// neighbouring trial DMs, a thread = 8 consecutive samples (two packed dwords) of every DM of the block.
+// For each channel the 8 samples at t + delay(dm, c) are 12 bytes fetched with ONE 16-byte-or-less load
+// per lane (the delay is uniform over the wave: its aligned part goes into the scalar offset of the
+// load, its low two bits into v_alignbyte) instead of eight 1-byte loads, and neighbouring DMs of the
+// block hit the same cache lines.  The bytes are summed as packed 16-bit pairs (v_pk_add_u16), widened to
+// 32 bits every 256 channels (256 x 255 < 2^16).  Integer arithmetic: the sums are exact whatever the order.
+#define DDM_DB 4
+#define DDM_SAMPLES 8
+#define DDM_TILE (256 * DDM_SAMPLES)
+#define DDM_ZAPPED INT32_MIN
+
 __global__ __launch_bounds__(256) void k_dedisperse(const uint8_t *__restrict__ xt, const int32_t *__restrict__ delay,
-                                                    uint32_t *__restrict__ D, int nchan, int tout, size_t tpitch,
-                                                    size_t dpitch)
+                                                    uint32_t *__restrict__ D, int nchan, int ndm, int tout,
+                                                    size_t tpitch, size_t dpitch)
 {
-    const int dm = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int32_t *dl = delay + (size_t)dm * nchan;
-    if (t >= tout) return;
-    uint32_t acc = 0;
-    for (int c = 0; c < nchan; ++c) {
-        const int32_t d = dl[c];        // uniform -> scalar load
-        if (d < 0) continue;
-        acc += xt[(size_t)c * tpitch + t + d];
+    const int dm0 = blockIdx.y * DDM_DB;
+    const int t = blockIdx.x * DDM_TILE + threadIdx.x * DDM_SAMPLES;      // 8-byte aligned (tpitch is a multiple of 64)
+    uint32_t lo[DDM_DB][2], hi[DDM_DB][2];      // packed u16 partial sums: bytes 0,2 / 1,3 of each of the two dwords
+    uint32_t acc[DDM_DB][DDM_SAMPLES];
+#pragma unroll
+    for (int j = 0; j < DDM_DB; ++j) {
+        lo[j][0] = lo[j][1] = hi[j][0] = hi[j][1] = 0u;
+#pragma unroll
+        for (int i = 0; i < DDM_SAMPLES; ++i) acc[j][i] = 0u;
     }
-    D[(size_t)dm * dpitch + t] = acc;
+    auto flush = [&]() {
+#pragma unroll
+        for (int j = 0; j < DDM_DB; ++j) {
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                acc[j][4 * w + 0] += lo[j][w] & 0xffffu;
+                acc[j][4 * w + 1] += hi[j][w] & 0xffffu;
+                acc[j][4 * w + 2] += lo[j][w] >> 16;
+                acc[j][4 * w + 3] += hi[j][w] >> 16;
+                lo[j][w] = hi[j][w] = 0u;
+            }
+        }
+    };
+    int since = 0;
+    for (int c = 0; c < nchan; ++c) {
+        const uint8_t *row = xt + (size_t)c * tpitch + t;
+#pragma unroll
+        for (int j = 0; j < DDM_DB; ++j) {
+            const int dm = dm0 + j < ndm ? dm0 + j : ndm - 1;
+            const int32_t d = delay[(size_t)dm * nchan + c];        // uniform -> scalar load
+            if (d == DDM_ZAPPED) continue;                           // (the same channels for every DM)
+            // samples t+d .. t+d+7: three aligned dwords starting at (t + d) & ~3
+            const uint32_t *p = (const uint32_t *)(row + (d & ~3));
+            const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+            const unsigned sh = (unsigned)(d & 3);
+            const uint32_t a = __builtin_amdgcn_alignbyte(w1, w0, sh);     // bytes sh.. of w1:w0
+            const uint32_t b = __builtin_amdgcn_alignbyte(w2, w1, sh);
+            lo[j][0] += a & 0x00ff00ffu;
+            hi[j][0] += (a >> 8) & 0x00ff00ffu;
+            lo[j][1] += b & 0x00ff00ffu;
+            hi[j][1] += (b >> 8) & 0x00ff00ffu;
+        }
+        if (++since == 256) {
+            flush();
+            since = 0;
+        }
+    }
+    flush();
+#pragma unroll
+    for (int j = 0; j < DDM_DB; ++j) {
+        if (dm0 + j >= ndm) break;
+        uint32_t *out = D + (size_t)(dm0 + j) * dpitch + t;
+        if (t + DDM_SAMPLES <= tout) {
+            *(uint4 *)out = make_uint4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+            *(uint4 *)(out + 4) = make_uint4(acc[j][4], acc[j][5], acc[j][6], acc[j][7]);
+        } else {
+            for (int i = 0; i < DDM_SAMPLES; ++i)
+                if (t + i < tout) out[i] = acc[j][i];
+        }
+    }
 }
 
 __device__ __forceinline__ double block_sum(double v, double *sh)
@@ -101,15 +169,60 @@ __device__ __forceinline__ double block_sum(double v, double *sh)
     return r;
 }
 
-// mean and rms of each DM series, then once more over the samples within 3 rms of the mean
-__global__ __launch_bounds__(256) void k_series_stats(const uint32_t *__restrict__ D, float *__restrict__ stats,
-                                                      int tout, size_t dpitch)
+// Inclusive prefix sums of each DM series (64-bit: a series sums to ~2e10), P[0] = 0: boxcar sums and the
+// running baseline become differences of two entries.  One workgroup per DM.
+__global__ __launch_bounds__(256) void k_prefix(const uint32_t *__restrict__ D, uint64_t *__restrict__ P, int tout,
+                                                size_t dpitch, size_t ppitch)
+{
+    __shared__ uint64_t sh[256];
+    const uint32_t *x = D + (size_t)blockIdx.x * dpitch;
+    uint64_t *p = P + (size_t)blockIdx.x * ppitch;
+    const int per = (tout + 255) / 256;
+    const int lo = threadIdx.x * per, hi = min(lo + per, tout);
+    uint64_t s = 0;
+    for (int t = lo; t < hi; ++t) s += x[t];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const uint64_t v = sh[i];
+            sh[i] = run;
+            run += v;
+        }
+        p[0] = 0;
+    }
+    __syncthreads();
+    uint64_t run = sh[threadIdx.x];
+    for (int t = lo; t < hi; ++t) {
+        run += x[t];
+        p[t + 1] = run;
+    }
+}
+
+// baseline under sample t: the mean of the series over the W samples around it (window clamped to the
+// series), or the per-series constant when W == 0
+__device__ __forceinline__ float baseline_at(const uint64_t *__restrict__ p, int t, int W, int tout, float gmean)
+{
+    if (W <= 0) return gmean;
+    int lo = t - W / 2, hi = lo + W;
+    if (lo < 0) { lo = 0; hi = min(W, tout); }
+    if (hi > tout) { hi = tout; lo = max(0, tout - W); }
+    return (float)((double)(p[hi] - p[lo]) / (double)(hi - lo));
+}
+
+// mean and rms of each DM series about its baseline, then once more over the samples within 3 rms
+__global__ __launch_bounds__(256) void k_series_stats(const uint32_t *__restrict__ D, const uint64_t *__restrict__ P,
+                                                      float *__restrict__ stats, int tout, int W, size_t dpitch,
+                                                      size_t ppitch)
 {
     __shared__ double sh[4];
     const uint32_t *x = D + (size_t)blockIdx.x * dpitch;
+    const uint64_t *p = P + (size_t)blockIdx.x * ppitch;
+    const float gmean0 = (float)((double)p[tout] / (double)tout);
     double s1 = 0, s2 = 0;
     for (int t = threadIdx.x; t < tout; t += 256) {
-        const double v = x[t];
+        const double v = (double)x[t] - (double)baseline_at(p, t, W, tout, gmean0);
         s1 += v;
         s2 += v * v;
     }
@@ -119,7 +232,7 @@ __global__ __launch_bounds__(256) void k_series_stats(const uint32_t *__restrict
     double rms = sqrt(var > 0 ? var : 0);
     double c1 = 0, c2 = 0, cn = 0;
     for (int t = threadIdx.x; t < tout; t += 256) {
-        const double v = x[t];
+        const double v = (double)x[t] - (double)baseline_at(p, t, W, tout, gmean0);
         if (fabs(v - mean) <= 3 * rms) {
             c1 += v;
             c2 += v * v;
@@ -136,36 +249,48 @@ __global__ __launch_bounds__(256) void k_series_stats(const uint32_t *__restrict
         rms = sqrt((var > 0 ? var : 0) / 0.97330);
     }
     if (threadIdx.x == 0) {
-        stats[2 * blockIdx.x] = (float)mean;
+        // [0]: level to subtract on top of the running baseline (W > 0) or the clipped mean itself (W == 0)
+        stats[2 * blockIdx.x] = (float)(W > 0 ? mean : mean + (double)gmean0);
         stats[2 * blockIdx.x + 1] = (float)rms;
     }
 }
 
-__global__ __launch_bounds__(256) void k_boxcar(const uint32_t *__restrict__ D, const float *__restrict__ stats,
+// best boxcar per (DM, sample) from prefix sums; samples at or above `thresh` also go to the peak list
+__global__ __launch_bounds__(256) void k_boxcar(const uint64_t *__restrict__ P, const float *__restrict__ stats,
                                                 float *__restrict__ snr, uint8_t *__restrict__ wid, int tout,
-                                                int nbox, size_t dpitch)
+                                                int nbox, int W, size_t dpitch, size_t ppitch, float thresh,
+                                                int32_t *__restrict__ peaks, int max_peaks)
 {
     const int dm = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= tout) return;
-    const uint32_t *x = D + (size_t)dm * dpitch;
-    const float mean = stats[2 * dm], rms = stats[2 * dm + 1];
+    const uint64_t *p = P + (size_t)dm * ppitch;
+    const float lvl = stats[2 * dm], rms = stats[2 * dm + 1];
     float best = -1e30f;
     int bw = 0;
-    uint32_t acc = 0;
-    int have = 0;
     for (int k = 0; k < nbox; ++k) {
         const int w = 1 << k;
         if (t + w > tout) break;
-        for (; have < w; ++have) acc += x[t + have];
-        const float s = ((float)acc - (float)w * mean) / (rms * sqrtf((float)w));
-        if (s > best) {
-            best = s;
+        const float sum = (float)(p[t + w] - p[t]);
+        const float base = W > 0 ? baseline_at(p, t + w / 2, W, tout, 0.f) + lvl : lvl;
+        const float sn = (sum - (float)w * base) / (rms * sqrtf((float)w));
+        if (sn > best) {
+            best = sn;
             bw = k;
         }
     }
-    snr[(size_t)dm * dpitch + t] = rms > 0 ? best : 0.f;
+    if (!(rms > 0)) best = 0.f;
+    snr[(size_t)dm * dpitch + t] = best;
     wid[(size_t)dm * dpitch + t] = (uint8_t)bw;
+    if (peaks && best >= thresh) {
+        const int i = atomicAdd(peaks, 1);
+        if (i < max_peaks) {
+            peaks[1 + 4 * i] = dm;
+            peaks[2 + 4 * i] = t;
+            peaks[3 + 4 * i] = __float_as_int(best);
+            peaks[4 + 4 * i] = bw;
+        }
+    }
 }
 
 extern "C" const char *pb_search_last_error(const pb_search *s) { return s ? s->err.c_str() : g_search_err.c_str(); }
@@ -176,6 +301,11 @@ extern "C" int pb_search_create(int device, int nchan, int max_samples, float fc
 {
     if (!out || nchan < 1 || max_samples < 64 || !(dm_step > 0) || dm_max < dm_min || boxcar_max < 1) {
         g_search_err = "pb_search_create: bad argument";
+        return PB_EINVAL;
+    }
+    if (!(dm_min >= 0) || device < 0) {
+        // a negative DM would give negative delays (reads before the block); a negative device goes to hipSetDevice
+        g_search_err = "pb_search_create: dm_min and device must be >= 0";
         return PB_EINVAL;
     }
     *out = nullptr;
@@ -201,6 +331,13 @@ extern "C" int pb_search_create(int device, int nchan, int max_samples, float fc
     s->d_D = nullptr;
     s->d_stats = s->d_snr = nullptr;
     s->stream = nullptr;
+    s->d_P = nullptr;
+    s->d_peaks = nullptr;
+    s->max_peaks = 1 << 20;
+    s->baseline = 0;
+    s->last_tout = 0;
+    for (int i = 0; i < 6; ++i) s->ms[i] = 0.f;
+    for (int i = 0; i < 7; ++i) s->ev[i] = nullptr;
     // delay table in double on the host; the top of the band (highest frequency) is the reference
     std::vector<int32_t> delay((size_t)s->ndm * nchan);
     const double ftop = foff_mhz < 0 ? fch1_mhz : fch1_mhz + (nchan - 1) * foff_mhz;
@@ -214,7 +351,7 @@ extern "C" int pb_search_create(int device, int nchan, int max_samples, float fc
             const double f = (double)fch1_mhz + (double)c * (double)foff_mhz;
             const double d = 4.148808e3 * dm * (1.0 / (f * f) - 1.0 / (ftop * ftop)) / (double)tsamp_s;
             const int32_t di = (int32_t)floor(d + 0.5);
-            delay[(size_t)i * nchan + c] = zap ? -1 : di;
+            delay[(size_t)i * nchan + c] = zap ? DDM_ZAPPED : di;
             if (!zap && di > maxd) maxd = di;
         }
     }
@@ -223,12 +360,17 @@ extern "C" int pb_search_create(int device, int nchan, int max_samples, float fc
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_codes, (size_t)max_samples * nchan);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_xt, s->tpitch * nchan);
+    // + 64: the dedispersion kernel fetches whole dwords around its 8 samples (up to 11 bytes past the last one)
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_xt, s->tpitch * nchan + 64);
+    if (e == hipSuccess) e = hipMemset(s->d_xt, 0, s->tpitch * nchan + 64);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_delay, delay.size() * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_D, (size_t)s->ndm * s->tpitch * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_stats, (size_t)s->ndm * 2 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_snr, (size_t)s->ndm * s->tpitch * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_wid, (size_t)s->ndm * s->tpitch);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_P, (size_t)s->ndm * (s->tpitch + 8) * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_peaks, (size_t)(1 + 4 * s->max_peaks) * sizeof(int32_t));
+    for (int i = 0; i < 7 && e == hipSuccess; ++i) e = hipEventCreate(&s->ev[i]);
     if (e == hipSuccess) e = hipMemcpy(s->d_delay, delay.data(), delay.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         g_search_err = std::string("pb_search_create: ") + hipGetErrorString(e);
@@ -244,7 +386,9 @@ extern "C" void pb_search_destroy(pb_search *s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void *p[] = {s->d_codes, s->d_xt, s->d_delay, s->d_D, s->d_stats, s->d_snr, s->d_wid};
+    void *p[] = {s->d_codes, s->d_xt, s->d_delay, s->d_D, s->d_stats, s->d_snr, s->d_wid, s->d_P, s->d_peaks};
+    for (int i = 0; i < 7; ++i)
+        if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
     for (void *q : p)
         if (q) (void)hipFree(q);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -260,11 +404,15 @@ extern "C" int pb_search_info(const pb_search *s, int *ndm, int *nbox, int *max_
     return PB_OK;
 }
 
-// codes: nsamp x nchan samples of nbit bits in SIGPROC order (host, or device if codes_on_device).
-// Outputs (host, any may be NULL): snr [ndm][tout] float, width_log2 [ndm][tout] u8,
-// series [ndm][tout] u32 (the dedispersed sums), stats [ndm][2]; tout = nsamp - max_delay.
-extern "C" int pb_search_run(pb_search *s, const void *codes, int codes_on_device, int nsamp, int nbit, float *snr,
-                             uint8_t *width_log2, uint32_t *series, float *stats, int *tout_out)
+extern "C" int pb_search_set_baseline(pb_search *s, int window_samples)
+{
+    if (!s || window_samples < 0) return PB_EINVAL;
+    s->baseline = window_samples;
+    return PB_OK;
+}
+
+static int search_run(pb_search *s, const void *codes, int codes_on_device, int nsamp, int nbit, float thresh,
+                      bool want_peaks)
 {
     if (!s || !codes) return PB_EINVAL;
     if (nsamp > s->max_samples || !(nbit == 8 || nbit == 4 || nbit == 2)) {
@@ -279,22 +427,86 @@ extern "C" int pb_search_run(pb_search *s, const void *codes, int codes_on_devic
     SCHK(s, hipSetDevice(s->device));
     const size_t nbytes = (size_t)nsamp * s->nchan * nbit / 8;
     const uint8_t *d_codes = (const uint8_t *)codes;
+    SCHK(s, hipEventRecord(s->ev[0], s->stream));
     if (!codes_on_device) {
         SCHK(s, hipMemcpyAsync(s->d_codes, codes, nbytes, hipMemcpyHostToDevice, s->stream));
         d_codes = s->d_codes;
     }
+    SCHK(s, hipEventRecord(s->ev[1], s->stream));
     dim3 gt((nsamp + 63) / 64, (s->nchan + 63) / 64);
     k_transpose_codes<<<gt, 256, 0, s->stream>>>(d_codes, s->d_xt, nsamp, s->nchan, nbit, s->tpitch);
+    SCHK(s, hipEventRecord(s->ev[2], s->stream));
     dim3 gd((tout + 255) / 256, s->ndm);
-    k_dedisperse<<<gd, 256, 0, s->stream>>>(s->d_xt, s->d_delay, s->d_D, s->nchan, tout, s->tpitch, s->tpitch);
-    k_series_stats<<<s->ndm, 256, 0, s->stream>>>(s->d_D, s->d_stats, tout, s->tpitch);
-    k_boxcar<<<gd, 256, 0, s->stream>>>(s->d_D, s->d_stats, s->d_snr, s->d_wid, tout, s->nbox, s->tpitch);
+    dim3 gdd((tout + DDM_TILE - 1) / DDM_TILE, (s->ndm + DDM_DB - 1) / DDM_DB);
+    k_dedisperse<<<gdd, 256, 0, s->stream>>>(s->d_xt, s->d_delay, s->d_D, s->nchan, s->ndm, tout, s->tpitch, s->tpitch);
+    SCHK(s, hipEventRecord(s->ev[3], s->stream));
+    const size_t ppitch = s->tpitch + 8;
+    k_prefix<<<s->ndm, 256, 0, s->stream>>>(s->d_D, s->d_P, tout, s->tpitch, ppitch);
+    k_series_stats<<<s->ndm, 256, 0, s->stream>>>(s->d_D, s->d_P, s->d_stats, tout, s->baseline, s->tpitch, ppitch);
+    SCHK(s, hipEventRecord(s->ev[4], s->stream));
+    if (want_peaks) SCHK(s, hipMemsetAsync(s->d_peaks, 0, sizeof(int32_t), s->stream));
+    k_boxcar<<<gd, 256, 0, s->stream>>>(s->d_P, s->d_stats, s->d_snr, s->d_wid, tout, s->nbox, s->baseline, s->tpitch,
+                                        ppitch, thresh, want_peaks ? s->d_peaks : nullptr, s->max_peaks);
+    SCHK(s, hipEventRecord(s->ev[5], s->stream));
     SCHK(s, hipGetLastError());
+    s->last_tout = tout;
+    return PB_OK;
+}
+
+static void search_times(pb_search *s)
+{
+    for (int i = 0; i < 6; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s->ev[i], s->ev[i + 1]) == hipSuccess) s->ms[i] = ms;
+    }
+}
+
+// codes: nsamp x nchan samples of nbit bits in SIGPROC order (host, or device if codes_on_device).
+// Outputs (host, any may be NULL): snr [ndm][tout] float, width_log2 [ndm][tout] u8,
+// series [ndm][tout] u32 (the dedispersed sums), stats [ndm][2]; tout = nsamp - max_delay.
+extern "C" int pb_search_run(pb_search *s, const void *codes, int codes_on_device, int nsamp, int nbit, float *snr,
+                             uint8_t *width_log2, uint32_t *series, float *stats, int *tout_out)
+{
+    int rc = search_run(s, codes, codes_on_device, nsamp, nbit, 0.f, false);
+    if (rc) return rc;
+    const int tout = s->last_tout;
     SCHK(s, hipStreamSynchronize(s->stream));
     if (snr) SCHK(s, hipMemcpy2D(snr, tout * sizeof(float), s->d_snr, s->tpitch * sizeof(float), tout * sizeof(float), s->ndm, hipMemcpyDeviceToHost));
     if (width_log2) SCHK(s, hipMemcpy2D(width_log2, tout, s->d_wid, s->tpitch, tout, s->ndm, hipMemcpyDeviceToHost));
     if (series) SCHK(s, hipMemcpy2D(series, tout * sizeof(uint32_t), s->d_D, s->tpitch * sizeof(uint32_t), tout * sizeof(uint32_t), s->ndm, hipMemcpyDeviceToHost));
     if (stats) SCHK(s, hipMemcpy(stats, s->d_stats, (size_t)s->ndm * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    SCHK(s, hipEventRecord(s->ev[6], s->stream));
+    SCHK(s, hipEventSynchronize(s->ev[6]));
+    search_times(s);
     if (tout_out) *tout_out = tout;
+    return PB_OK;
+}
+
+// The search as the production chain uses it: only the (DM, sample) points at or above `threshold` come back
+// (what heimdall's giant finder starts from), not the S/N planes: peaks[4 i ..] = DM index, sample, S/N
+// (float bits), log2 width; *npeaks may exceed max_out when the list was truncated.
+extern "C" int pb_search_peaks(pb_search *s, const void *codes, int codes_on_device, int nsamp, int nbit,
+                               float threshold, int32_t *peaks, int max_out, int *npeaks, int *tout_out)
+{
+    if (!peaks || !npeaks || max_out < 1) return PB_EINVAL;
+    int rc = search_run(s, codes, codes_on_device, nsamp, nbit, threshold, true);
+    if (rc) return rc;
+    int32_t n = 0;
+    SCHK(s, hipMemcpyAsync(&n, s->d_peaks, sizeof n, hipMemcpyDeviceToHost, s->stream));
+    SCHK(s, hipStreamSynchronize(s->stream));
+    const int ncopy = n < max_out ? (n < s->max_peaks ? n : s->max_peaks) : max_out;
+    if (ncopy > 0) SCHK(s, hipMemcpy(peaks, s->d_peaks + 1, (size_t)ncopy * 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    SCHK(s, hipEventRecord(s->ev[6], s->stream));
+    SCHK(s, hipEventSynchronize(s->ev[6]));
+    search_times(s);
+    *npeaks = n;
+    if (tout_out) *tout_out = s->last_tout;
+    return PB_OK;
+}
+
+extern "C" int pb_search_timers(const pb_search *s, float *ms6)
+{
+    if (!s || !ms6) return PB_EINVAL;
+    for (int i = 0; i < 6; ++i) ms6[i] = s->ms[i];
     return PB_OK;
 }

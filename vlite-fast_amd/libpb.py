@@ -54,7 +54,8 @@ EXPORTS = ["pb_config_default", "pb_create", "pb_destroy", "pb_last_error", "pb_
            "pb_submit_planar", "pb_submit_planar_dev", "pb_submit_vdif", "pb_submit_vdif_at", "pb_input_dev", "pb_process", "pb_set_frb_params", "pb_select_set", "pb_fetch", "pb_fetch_ptr",
            "pb_output_dev", "pb_coadd_local", "pb_set_coadd_stream", "pb_coadd_finish", "pb_coadd_fetch_ptr", "pb_profile", "pb_get_timers",
            "pb_debug_fetch", "pb_channelize_f32", "pb_version", "pb_search_create", "pb_search_destroy",
-           "pb_search_last_error", "pb_search_info", "pb_search_run"]
+           "pb_search_last_error", "pb_search_info", "pb_search_run", "pb_search_set_baseline", "pb_search_peaks",
+           "pb_search_timers"]
 
 _lib = None
 
@@ -121,6 +122,9 @@ def load():
     L.pb_search_last_error.restype = C.c_char_p
     L.pb_search_info.argtypes = [vp, ip, ip, ip]
     L.pb_search_run.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, fp, u8p, C.POINTER(C.c_uint32), fp, ip]
+    L.pb_search_set_baseline.argtypes = [vp, C.c_int]
+    L.pb_search_peaks.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int32), C.c_int, ip, ip]
+    L.pb_search_timers.argtypes = [vp, fp]
     for n in EXPORTS:
         f = getattr(L, n)
         if f.restype is C.c_int or n in ("pb_create", "pb_query", "pb_sync"):

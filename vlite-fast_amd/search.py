@@ -61,6 +61,39 @@ class Searcher(object):
         except Exception:
             pass
 
+    def set_baseline(self, window_samples):
+        """running baseline over this many samples (heimdall: 2 s = 2560); 0 = one clipped mean per series"""
+        rc = self._L.pb_search_set_baseline(self._s, int(window_samples))
+        if rc != 0:
+            raise ValueError("baseline window must be >= 0")
+
+    def timers(self):
+        """device ms of the last run's stages"""
+        t = (C.c_float * 6)()
+        self._L.pb_search_timers(self._s, t)
+        return dict(zip(("h2d", "transpose", "dedisperse", "stats", "boxcar", "d2h"), [float(v) for v in t]))
+
+    def peaks(self, codes, threshold, nbit=8, device_ptr=None, nsamp=None, max_out=1 << 18):
+        """Search one block and return only the (DM, sample) points with S/N >= threshold:
+        dict(dmi, t, snr, width_log2, total).  codes: host uint8 array, or device_ptr + nsamp for codes that
+        are already on the GPU (e.g. PbHandle.output_dev)."""
+        if device_ptr is None:
+            codes = np.ascontiguousarray(codes, np.uint8).ravel()
+            nsamp = codes.size * (8 // nbit) // self.nchan
+            ptr, on_dev = codes.ctypes.data_as(C.c_void_p), 0
+        else:
+            ptr, on_dev = C.c_void_p(device_ptr), 1
+        buf = np.empty((max_out, 4), np.int32)
+        n, t = C.c_int(), C.c_int()
+        rc = self._L.pb_search_peaks(self._s, ptr, on_dev, nsamp, nbit, C.c_float(threshold),
+                                     buf.ctypes.data_as(C.POINTER(C.c_int32)), max_out, C.byref(n), C.byref(t))
+        if rc != 0:
+            raise self._lp.PbError("pb_search_peaks failed (%d): %s" % (rc, self._L.pb_search_last_error(self._s).decode()))
+        k = min(n.value, max_out)
+        b = buf[:k]
+        return dict(dmi=b[:, 0].copy(), t=b[:, 1].copy(), snr=b[:, 2].copy().view(np.float32), width_log2=b[:, 3].astype(np.uint8),
+                    total=n.value, tout=t.value)
+
     def run(self, codes, nbit=8, want_series=False):
         """codes: uint8 array holding nsamp x nchan samples of nbit bits (SIGPROC order).
         Returns dict(snr [ndm][tout] f32, width_log2 [ndm][tout] u8, stats [ndm][2], series?)."""
@@ -107,6 +140,61 @@ def find_candidates(snr, width_log2, dms, tsamp, threshold=6.0, dm_tol=0.1, samp
                           tfilt=int(np.log2(w[k])), dmi=int(idm[k]), dm=float(dm), ngiant=int(near.sum()),
                           i0=int(sample0 + it[near].min()), i1=int(sample0 + (it[near] + w[near]).max())))
     return cands
+
+
+def candidates_from_peaks(pk, dms, tsamp, dm_tol=0.1, sample0=0):
+    """find_candidates on a peak list (Searcher.peaks) instead of full S/N planes"""
+    idm, it, sn, w = pk["dmi"].astype(np.int64), pk["t"].astype(np.int64), pk["snr"], (1 << pk["width_log2"].astype(np.int64))
+    if idm.size == 0:
+        return []
+    order = np.argsort(-sn, kind="stable")
+    idm, it, sn, w = idm[order], it[order], sn[order], w[order]
+    taken = np.zeros(idm.size, bool)
+    cands = []
+    for k in range(idm.size):
+        if taken[k]:
+            continue
+        i0, i1, dm = it[k], it[k] + w[k], dms[idm[k]]
+        near = (~taken) & (it < i1) & (it + w > i0) & (np.abs(dms[idm] - dm) <= dm_tol * max(dm, 1.0) + 1e-9)
+        taken |= near
+        cands.append(dict(snr=float(sn[k]), peak_idx=int(sample0 + it[k]), peak_time=float((sample0 + it[k]) * tsamp),
+                          tfilt=int(np.log2(w[k])), dmi=int(idm[k]), dm=float(dm), ngiant=int(near.sum()),
+                          i0=int(sample0 + it[near].min()), i1=int(sample0 + (it[near] + w[near]).max())))
+    return cands
+
+
+class GulpSearch(object):
+    """The search over a stream of filterbank samples in gulps, as heimdall runs it (-nsamps_gulp 30720,
+    scripts/start_heimdall_single_antenna:21): every gulp is searched together with the last max_delay
+    samples of the stream before it, so that each output sample is produced exactly once and a pulse
+    whose sweep straddles a gulp boundary is not lost.  push() returns the candidates of the samples that
+    became complete; sample indices count from the start of the stream."""
+
+    def __init__(self, searcher, threshold=6.0, nbit=8, coincidencer=None, utc_start="1970-01-01-00:00:00", beam=1):
+        self.s, self.threshold, self.nbit = searcher, threshold, nbit
+        self.tail = np.zeros((0, searcher.nchan), np.uint8)
+        self.done = 0                    # output samples produced so far = stream index of the next block's first output
+        self.coincidencer, self.utc_start, self.beam = coincidencer, utc_start, beam
+
+    def push(self, block):
+        """block: uint8 [nsamp][nchan] (8-bit codes) of NEW samples"""
+        if self.nbit != 8:
+            raise ValueError("GulpSearch takes unpacked 8-bit samples")
+        block = np.asarray(block, np.uint8).reshape(-1, self.s.nchan)
+        data = np.concatenate([self.tail, block]) if self.tail.size else block
+        keep = min(self.s.max_delay, data.shape[0])
+        if data.shape[0] - self.s.max_delay < 64:
+            self.tail = data                          # not enough yet for one output block
+            return []
+        pk = self.s.peaks(data, self.threshold, nbit=8)
+        cands = candidates_from_peaks(pk, self.s.dms, self.s.tsamp, sample0=self.done)
+        self.done += pk["tout"]
+        self.tail = data[data.shape[0] - keep:].copy()
+        if self.coincidencer:
+            cmod = importlib.import_module(_pkg + ".candidates")
+            host, port = cmod.parse_coincidencer(self.coincidencer)
+            cmod.send_candidates(host, port, self.utc_start, self.beam, cands, first_sample=self.done - pk["tout"], nsamps=pk["tout"])
+        return cands
 
 
 def candidate_line(c):
