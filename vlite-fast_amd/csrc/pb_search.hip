@@ -26,7 +26,9 @@ struct pb_search {
     float fch1, foff, tsamp, dm_min, dm_step;
     int max_delay;
     uint8_t *d_codes, *d_xt;       // raw block; channel-major [nchan][tpitch]
-    int32_t *d_delay;              // [ndm][nchan], INT32_MIN = zapped channel
+    int32_t *d_delay;              // [ndm][nact] delays of the channels that are not zapped
+    int32_t *d_chans;              // [nact] their indices
+    int nact;
     uint32_t *d_D;                 // [ndm][max_samples]
     float *d_stats;                // [ndm][2] mean, rms
     float *d_snr;                  // [ndm][max_samples]
@@ -86,22 +88,32 @@ __global__ __launch_bounds__(256) void k_transpose_codes(const uint8_t *__restri
 // load, its low two bits into v_alignbyte) instead of eight 1-byte loads, and neighbouring DMs of the
 // block hit the same cache lines.  The bytes are summed as packed 16-bit pairs (v_pk_add_u16), widened to
 // 32 bits every 256 channels (256 x 255 < 2^16).  Integer arithmetic: the sums are exact whatever the order.
+#ifndef DDM_DB
 #define DDM_DB 4
+#endif
+#ifndef DDM_SAMPLES
 #define DDM_SAMPLES 8
+#endif
+#ifndef DDM_CU
+#define DDM_CU 4          // channels whose loads are in flight together
+#endif
 #define DDM_TILE (256 * DDM_SAMPLES)
-#define DDM_ZAPPED INT32_MIN
 
-__global__ __launch_bounds__(256) void k_dedisperse(const uint8_t *__restrict__ xt, const int32_t *__restrict__ delay,
-                                                    uint32_t *__restrict__ D, int nchan, int ndm, int tout,
-                                                    size_t tpitch, size_t dpitch)
+// chans: the nact channels that are not zapped; delay: [ndm][nact] over those channels
+__global__ __launch_bounds__(256) void k_dedisperse(const uint8_t *__restrict__ xt, const int32_t *__restrict__ chans,
+                                                    const int32_t *__restrict__ delay, uint32_t *__restrict__ D,
+                                                    int nact, int ndm, int tout, size_t tpitch, size_t dpitch)
 {
     const int dm0 = blockIdx.y * DDM_DB;
-    const int t = blockIdx.x * DDM_TILE + threadIdx.x * DDM_SAMPLES;      // 8-byte aligned (tpitch is a multiple of 64)
-    uint32_t lo[DDM_DB][2], hi[DDM_DB][2];      // packed u16 partial sums: bytes 0,2 / 1,3 of each of the two dwords
+    const int t = blockIdx.x * DDM_TILE + threadIdx.x * DDM_SAMPLES;      // 4-byte aligned (tpitch is a multiple of 64)
+    uint32_t lo[DDM_DB][DDM_SAMPLES / 4], hi[DDM_DB][DDM_SAMPLES / 4];   // packed u16 partial sums: bytes 0,2 / 1,3
     uint32_t acc[DDM_DB][DDM_SAMPLES];
+    const int32_t *dl[DDM_DB];
 #pragma unroll
     for (int j = 0; j < DDM_DB; ++j) {
-        lo[j][0] = lo[j][1] = hi[j][0] = hi[j][1] = 0u;
+        dl[j] = delay + (size_t)(dm0 + j < ndm ? dm0 + j : ndm - 1) * nact;
+#pragma unroll
+        for (int w = 0; w < DDM_SAMPLES / 4; ++w) lo[j][w] = hi[j][w] = 0u;
 #pragma unroll
         for (int i = 0; i < DDM_SAMPLES; ++i) acc[j][i] = 0u;
     }
@@ -109,7 +121,7 @@ __global__ __launch_bounds__(256) void k_dedisperse(const uint8_t *__restrict__ 
 #pragma unroll
         for (int j = 0; j < DDM_DB; ++j) {
 #pragma unroll
-            for (int w = 0; w < 2; ++w) {
+            for (int w = 0; w < DDM_SAMPLES / 4; ++w) {
                 acc[j][4 * w + 0] += lo[j][w] & 0xffffu;
                 acc[j][4 * w + 1] += hi[j][w] & 0xffffu;
                 acc[j][4 * w + 2] += lo[j][w] >> 16;
@@ -118,28 +130,49 @@ __global__ __launch_bounds__(256) void k_dedisperse(const uint8_t *__restrict__ 
             }
         }
     };
-    int since = 0;
-    for (int c = 0; c < nchan; ++c) {
-        const uint8_t *row = xt + (size_t)c * tpitch + t;
+    // one channel of one DM: samples t+d .. t+d+DDM_SAMPLES-1 = DDM_SAMPLES/4 + 1 aligned dwords from (t + d) & ~3
+    auto fetch = [&](int c, int j, uint32_t (&w)[DDM_SAMPLES / 4 + 1], unsigned &sh) {
+        const int32_t d = dl[j][c];                                 // uniform -> scalar load
+        const uint32_t *p = (const uint32_t *)(xt + (size_t)chans[c] * tpitch + t + (d & ~3));
 #pragma unroll
-        for (int j = 0; j < DDM_DB; ++j) {
-            const int dm = dm0 + j < ndm ? dm0 + j : ndm - 1;
-            const int32_t d = delay[(size_t)dm * nchan + c];        // uniform -> scalar load
-            if (d == DDM_ZAPPED) continue;                           // (the same channels for every DM)
-            // samples t+d .. t+d+7: three aligned dwords starting at (t + d) & ~3
-            const uint32_t *p = (const uint32_t *)(row + (d & ~3));
-            const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
-            const unsigned sh = (unsigned)(d & 3);
-            const uint32_t a = __builtin_amdgcn_alignbyte(w1, w0, sh);     // bytes sh.. of w1:w0
-            const uint32_t b = __builtin_amdgcn_alignbyte(w2, w1, sh);
-            lo[j][0] += a & 0x00ff00ffu;
-            hi[j][0] += (a >> 8) & 0x00ff00ffu;
-            lo[j][1] += b & 0x00ff00ffu;
-            hi[j][1] += (b >> 8) & 0x00ff00ffu;
+        for (int i = 0; i <= DDM_SAMPLES / 4; ++i) w[i] = p[i];
+        sh = (unsigned)(d & 3);
+    };
+    auto add = [&](int j, const uint32_t (&w)[DDM_SAMPLES / 4 + 1], unsigned sh) {
+#pragma unroll
+        for (int i = 0; i < DDM_SAMPLES / 4; ++i) {
+            const uint32_t a = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);      // bytes sh.. of w[i+1]:w[i]
+            lo[j][i] += a & 0x00ff00ffu;
+            hi[j][i] += (a >> 8) & 0x00ff00ffu;
         }
-        if (++since == 256) {
+    };
+    // DDM_CU channels at a time: all their loads are issued before the first is used (the loop is bound by
+    // load latency, not by anything it computes)
+    int c = 0, since = 0;
+    for (; c + DDM_CU <= nact; c += DDM_CU) {
+        uint32_t w[DDM_CU][DDM_DB][DDM_SAMPLES / 4 + 1];
+        unsigned sh[DDM_CU][DDM_DB];
+#pragma unroll
+        for (int u = 0; u < DDM_CU; ++u)
+#pragma unroll
+            for (int j = 0; j < DDM_DB; ++j) fetch(c + u, j, w[u][j], sh[u][j]);
+#pragma unroll
+        for (int u = 0; u < DDM_CU; ++u)
+#pragma unroll
+            for (int j = 0; j < DDM_DB; ++j) add(j, w[u][j], sh[u][j]);
+        since += DDM_CU;
+        if (since >= 240) {                                     // 16-bit sums: at most 257 channels of 255 between flushes
             flush();
             since = 0;
+        }
+    }
+    for (; c < nact; ++c) {
+#pragma unroll
+        for (int j = 0; j < DDM_DB; ++j) {
+            uint32_t w[DDM_SAMPLES / 4 + 1];
+            unsigned sh;
+            fetch(c, j, w, sh);
+            add(j, w, sh);
         }
     }
     flush();
@@ -147,12 +180,14 @@ __global__ __launch_bounds__(256) void k_dedisperse(const uint8_t *__restrict__ 
     for (int j = 0; j < DDM_DB; ++j) {
         if (dm0 + j >= ndm) break;
         uint32_t *out = D + (size_t)(dm0 + j) * dpitch + t;
-        if (t + DDM_SAMPLES <= tout) {
-            *(uint4 *)out = make_uint4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
-            *(uint4 *)(out + 4) = make_uint4(acc[j][4], acc[j][5], acc[j][6], acc[j][7]);
-        } else {
-            for (int i = 0; i < DDM_SAMPLES; ++i)
-                if (t + i < tout) out[i] = acc[j][i];
+#pragma unroll
+        for (int i = 0; i < DDM_SAMPLES; i += 4) {
+            if (t + i + 4 <= tout) {
+                *(uint4 *)(out + i) = make_uint4(acc[j][i], acc[j][i + 1], acc[j][i + 2], acc[j][i + 3]);
+            } else {
+                for (int q = 0; q < 4; ++q)
+                    if (t + i + q < tout) out[i + q] = acc[j][i + q];
+            }
         }
     }
 }
@@ -328,6 +363,7 @@ extern "C" int pb_search_create(int device, int nchan, int max_samples, float fc
     while ((1 << s->nbox) <= boxcar_max) s->nbox++;
     s->d_codes = s->d_xt = s->d_wid = nullptr;
     s->d_delay = nullptr;
+    s->d_chans = nullptr;
     s->d_D = nullptr;
     s->d_stats = s->d_snr = nullptr;
     s->stream = nullptr;
@@ -339,20 +375,30 @@ extern "C" int pb_search_create(int device, int nchan, int max_samples, float fc
     for (int i = 0; i < 6; ++i) s->ms[i] = 0.f;
     for (int i = 0; i < 7; ++i) s->ev[i] = nullptr;
     // delay table in double on the host; the top of the band (highest frequency) is the reference
-    std::vector<int32_t> delay((size_t)s->ndm * nchan);
+    std::vector<int32_t> chans;
+    for (int c = 0; c < nchan; ++c) {
+        bool zap = false;
+        for (int z = 0; z < nzap; ++z)
+            if (c >= zap_ranges[2 * z] && c < zap_ranges[2 * z + 1]) zap = true;
+        if (!zap) chans.push_back(c);
+    }
+    s->nact = (int)chans.size();
+    if (s->nact == 0) {
+        g_search_err = "pb_search_create: every channel is zapped";
+        delete s;
+        return PB_EINVAL;
+    }
+    std::vector<int32_t> delay((size_t)s->ndm * s->nact);
     const double ftop = foff_mhz < 0 ? fch1_mhz : fch1_mhz + (nchan - 1) * foff_mhz;
     int maxd = 0;
     for (int i = 0; i < s->ndm; ++i) {
         const double dm = (double)dm_min + (double)i * (double)dm_step;
-        for (int c = 0; c < nchan; ++c) {
-            bool zap = false;
-            for (int z = 0; z < nzap; ++z)
-                if (c >= zap_ranges[2 * z] && c < zap_ranges[2 * z + 1]) zap = true;
-            const double f = (double)fch1_mhz + (double)c * (double)foff_mhz;
+        for (int k = 0; k < s->nact; ++k) {
+            const double f = (double)fch1_mhz + (double)chans[k] * (double)foff_mhz;
             const double d = 4.148808e3 * dm * (1.0 / (f * f) - 1.0 / (ftop * ftop)) / (double)tsamp_s;
             const int32_t di = (int32_t)floor(d + 0.5);
-            delay[(size_t)i * nchan + c] = zap ? DDM_ZAPPED : di;
-            if (!zap && di > maxd) maxd = di;
+            delay[(size_t)i * s->nact + k] = di;
+            if (di > maxd) maxd = di;
         }
     }
     s->max_delay = maxd;
@@ -364,6 +410,8 @@ extern "C" int pb_search_create(int device, int nchan, int max_samples, float fc
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_xt, s->tpitch * nchan + 64);
     if (e == hipSuccess) e = hipMemset(s->d_xt, 0, s->tpitch * nchan + 64);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_delay, delay.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_chans, chans.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpy(s->d_chans, chans.data(), chans.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_D, (size_t)s->ndm * s->tpitch * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_stats, (size_t)s->ndm * 2 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_snr, (size_t)s->ndm * s->tpitch * sizeof(float));
@@ -386,7 +434,7 @@ extern "C" void pb_search_destroy(pb_search *s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void *p[] = {s->d_codes, s->d_xt, s->d_delay, s->d_D, s->d_stats, s->d_snr, s->d_wid, s->d_P, s->d_peaks};
+    void *p[] = {s->d_codes, s->d_xt, s->d_delay, s->d_D, s->d_stats, s->d_snr, s->d_wid, s->d_P, s->d_peaks, s->d_chans};
     for (int i = 0; i < 7; ++i)
         if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
     for (void *q : p)
@@ -438,7 +486,7 @@ static int search_run(pb_search *s, const void *codes, int codes_on_device, int 
     SCHK(s, hipEventRecord(s->ev[2], s->stream));
     dim3 gd((tout + 255) / 256, s->ndm);
     dim3 gdd((tout + DDM_TILE - 1) / DDM_TILE, (s->ndm + DDM_DB - 1) / DDM_DB);
-    k_dedisperse<<<gdd, 256, 0, s->stream>>>(s->d_xt, s->d_delay, s->d_D, s->nchan, s->ndm, tout, s->tpitch, s->tpitch);
+    k_dedisperse<<<gdd, 256, 0, s->stream>>>(s->d_xt, s->d_chans, s->d_delay, s->d_D, s->nact, s->ndm, tout, s->tpitch, s->tpitch);
     SCHK(s, hipEventRecord(s->ev[3], s->stream));
     const size_t ppitch = s->tpitch + 8;
     k_prefix<<<s->ndm, 256, 0, s->stream>>>(s->d_D, s->d_P, tout, s->tpitch, ppitch);
