@@ -212,6 +212,10 @@ typedef struct pb_search pb_search;
 int pb_search_create(int device, int nchan, int max_samples, float fch1_mhz, float foff_mhz, float tsamp_s,
                      float dm_min, float dm_max, float dm_step, int boxcar_max, const int *zap_ranges,
                      int nzap, pb_search **out);
+/* The same over an explicit, strictly ascending list of trial DMs (e.g. search.dedisp_dm_list). */
+int pb_search_create_list(int device, int nchan, int max_samples, float fch1_mhz, float foff_mhz, float tsamp_s,
+                          const float *dm_list, int ndm, int boxcar_max, const int *zap_ranges, int nzap,
+                          pb_search **out);
 void pb_search_destroy(pb_search *s);
 const char *pb_search_last_error(const pb_search *s);
 int pb_search_info(const pb_search *s, int *ndm, int *nbox, int *max_delay);

@@ -173,3 +173,52 @@ def test_running_baseline_follows_a_drifting_level():
     # with one global mean per series the drift either buries the pulse or floods the list with false points
     g0 = search.candidates_from_peaks(glob, np.arange(21) * 4.0, tsamp)
     assert (not g0) or g0[0]["snr"] < 0.8 * flat["snr"] or glob["total"] > 20 * max(1, len(run))
+
+
+def test_dm_list_and_the_search_cli_on_a_fil(tmp_path, capsys):
+    """The tolerance-spaced trial DMs (dedisp's recursion) and heimdall's place in the chain end to end: a
+    SIGPROC file with a dispersed pulse -> gulps -> candidate lines -> the coincidencer's TCP port."""
+    import socket
+    import threading
+    sigproc = importlib.import_module("vlite-fast_amd.sigproc")
+    dml = search.dedisp_dm_list(2.0, 1000.0, search.TSAMP, search.FCH1, search.FOFF, 4096)
+    assert dml[0] == 2.0 and dml[-1] >= 1000.0 and np.all(np.diff(dml) > 0)
+    assert np.diff(dml)[0] < np.diff(dml)[-1]                    # steps grow with DM
+    assert 500 < dml.size < 5000                              # 2362 for this band (0.27 ... 0.78 pc cm^-3 steps)
+    nchan, T = 4096, 16384
+    dm, t0 = 150.0, 2500
+    codes, _ = _plane(76, T, nchan, dm, t0, 4, 0.35, search.FCH1, search.FOFF, search.TSAMP)
+    fil = tmp_path / "obs_kur.fil"
+    fil.write_bytes(sigproc.sigproc_header(7, 0.87, -0.72, "B0833-45", 57570 + 3600 / 86400., 1, 8) + codes.tobytes())
+    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    srv.bind(("127.0.0.1", 0))
+    srv.listen(8)
+    got = []
+
+    def serve():
+        srv.settimeout(20)
+        try:
+            while True:
+                c, _ = srv.accept()
+                buf = b""
+                while True:
+                    m = c.recv(4096)
+                    if not m:
+                        break
+                    buf += m
+                got.append(buf.decode())
+        except OSError:
+            pass
+
+    th = threading.Thread(target=serve, daemon=True)
+    th.start()
+    n = search.main(["-f", str(fil), "-dm", "2", "400", "-nsamps_gulp", "8192", "-zap_chans", "0", "190", "-zap_chans", "3900",
+                     "4096", "-detect_thresh", "7", "-beam", "8", "-coincidencer", "127.0.0.1:%d" % srv.getsockname()[1]])
+    srv.close()
+    th.join(timeout=5)
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    assert n == len(lines) >= 1
+    best = max((l.split() for l in lines), key=lambda t: float(t[0]))
+    assert abs(float(best[5]) - dm) < 15 and abs(int(best[1]) - t0) <= 4          # DM and stream sample of the pulse
+    assert len(got) >= 1 and got[0].split("\n")[0].split()[0] == "2016-07-01-01:00:00" and got[0].split("\n")[0].split()[3] == "8"
+    assert any(l.split()[1] == best[1] for g in got for l in g.split("\n")[2:] if l.strip())

@@ -330,11 +330,48 @@ __global__ __launch_bounds__(256) void k_boxcar(const uint64_t *__restrict__ P, 
 
 extern "C" const char *pb_search_last_error(const pb_search *s) { return s ? s->err.c_str() : g_search_err.c_str(); }
 
+static int search_create(int device, int nchan, int max_samples, float fch1_mhz, float foff_mhz, float tsamp_s,
+                         const std::vector<double> &dms, int boxcar_max, const int *zap_ranges, int nzap,
+                         pb_search **out);
+
 extern "C" int pb_search_create(int device, int nchan, int max_samples, float fch1_mhz, float foff_mhz, float tsamp_s,
                                 float dm_min, float dm_max, float dm_step, int boxcar_max, const int *zap_ranges,
                                 int nzap, pb_search **out)
 {
-    if (!out || nchan < 1 || max_samples < 64 || !(dm_step > 0) || dm_max < dm_min || boxcar_max < 1) {
+    if (!out || !(dm_step > 0) || dm_max < dm_min) {
+        g_search_err = "pb_search_create: bad argument";
+        return PB_EINVAL;
+    }
+    const int ndm = (int)floor((dm_max - dm_min) / dm_step + 1e-6) + 1;
+    std::vector<double> dms(ndm);
+    for (int i = 0; i < ndm; ++i) dms[i] = (double)dm_min + (double)i * (double)dm_step;
+    return search_create(device, nchan, max_samples, fch1_mhz, foff_mhz, tsamp_s, dms, boxcar_max, zap_ranges, nzap, out);
+}
+
+// The same over an explicit list of trial DMs (ascending), e.g. a tolerance-spaced one
+extern "C" int pb_search_create_list(int device, int nchan, int max_samples, float fch1_mhz, float foff_mhz,
+                                     float tsamp_s, const float *dm_list, int ndm, int boxcar_max,
+                                     const int *zap_ranges, int nzap, pb_search **out)
+{
+    if (!out || !dm_list || ndm < 1) {
+        g_search_err = "pb_search_create_list: bad argument";
+        return PB_EINVAL;
+    }
+    std::vector<double> dms(dm_list, dm_list + ndm);
+    for (int i = 1; i < ndm; ++i)
+        if (!(dms[i] > dms[i - 1])) {
+            g_search_err = "pb_search_create_list: the DM list must be strictly ascending";
+            return PB_EINVAL;
+        }
+    return search_create(device, nchan, max_samples, fch1_mhz, foff_mhz, tsamp_s, dms, boxcar_max, zap_ranges, nzap, out);
+}
+
+static int search_create(int device, int nchan, int max_samples, float fch1_mhz, float foff_mhz, float tsamp_s,
+                         const std::vector<double> &dms, int boxcar_max, const int *zap_ranges, int nzap,
+                         pb_search **out)
+{
+    const float dm_min = (float)dms.front();
+    if (!out || nchan < 1 || max_samples < 64 || boxcar_max < 1) {
         g_search_err = "pb_search_create: bad argument";
         return PB_EINVAL;
     }
@@ -357,8 +394,8 @@ extern "C" int pb_search_create(int device, int nchan, int max_samples, float fc
     s->foff = foff_mhz;
     s->tsamp = tsamp_s;
     s->dm_min = dm_min;
-    s->dm_step = dm_step;
-    s->ndm = (int)floor((dm_max - dm_min) / dm_step + 1e-6) + 1;
+    s->dm_step = dms.size() > 1 ? (float)(dms[1] - dms[0]) : 0.f;
+    s->ndm = (int)dms.size();
     s->nbox = 0;
     while ((1 << s->nbox) <= boxcar_max) s->nbox++;
     s->d_codes = s->d_xt = s->d_wid = nullptr;
@@ -392,7 +429,7 @@ extern "C" int pb_search_create(int device, int nchan, int max_samples, float fc
     const double ftop = foff_mhz < 0 ? fch1_mhz : fch1_mhz + (nchan - 1) * foff_mhz;
     int maxd = 0;
     for (int i = 0; i < s->ndm; ++i) {
-        const double dm = (double)dm_min + (double)i * (double)dm_step;
+        const double dm = dms[i];
         for (int k = 0; k < s->nact; ++k) {
             const double f = (double)fch1_mhz + (double)chans[k] * (double)foff_mhz;
             const double d = 4.148808e3 * dm * (1.0 / (f * f) - 1.0 / (ftop * ftop)) / (double)tsamp_s;

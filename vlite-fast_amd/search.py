@@ -25,24 +25,55 @@ FOFF = -64. / 6251
 TSAMP = 12500.0 / 128e6 * 8
 
 
+def dedisp_dm_list(dm_start, dm_end, tsamp, fch1, foff, nchan, tol=1.25, pulse_width_us=40.0):
+    """Trial DMs spaced so that the smearing of a pulse at one DM by the next step stays within `tol`:
+    the recursion of the dedisp library's generate_dm_list that heimdall runs on (-dm_tol 1.25,
+    -dm_pulse_width 40 are heimdall's defaults; dedisp/heimdall are third party, unpinned forks in the
+    reference's src/INSTALL and absent here: restated from the published algorithm, Barsdell et al. 2012
+    / Levin 2012 eq. 4.6; the candidate list it leads to stays parity-unpinned).
+        a = 8.3 df / f^3 (us per DM unit per channel, f = band centre in GHz, df in MHz)
+        dm' = (b2 dm + sqrt(-a2 b2 dm^2 + (a2 + b2) k)) / (a2 + b2),
+        a2 = a^2, b2 = a2 nchan^2 / 16, k = (dt^2 + w^2)(tol^2 - 1) + tol^2 a2 dm^2"""
+    dt = tsamp * 1e6
+    f = (fch1 + (nchan / 2 - 0.5) * foff) * 1e-3
+    tol2 = tol * tol
+    a = 8.3 * abs(foff) / (f * f * f)
+    a2 = a * a
+    b2 = a2 * (nchan * nchan / 16.0)
+    c = (dt * dt + pulse_width_us * pulse_width_us) * (tol2 - 1.0)
+    dms = [float(dm_start)]
+    while dms[-1] < dm_end:
+        prev = dms[-1]
+        k = c + tol2 * a2 * prev * prev
+        dms.append((b2 * prev + np.sqrt(-a2 * b2 * prev * prev + (a2 + b2) * k)) / (a2 + b2))
+    return np.asarray(dms, np.float32)
+
+
 class Searcher(object):
     def __init__(self, device=0, nchan=4096, max_samples=HEIMDALL_GULP, fch1=FCH1, foff=FOFF, tsamp=TSAMP,
                  dm_min=HEIMDALL_DM[0], dm_max=HEIMDALL_DM[1], dm_step=2.0, boxcar_max=HEIMDALL_BOXCAR_MAX,
-                 zap=HEIMDALL_ZAP):
+                 zap=HEIMDALL_ZAP, dm_list=None):
+        """dm_list: explicit trial DMs (e.g. dedisp_dm_list(...)); default the linear grid dm_min..dm_max"""
         lp = importlib.import_module(_pkg + ".libpb")
         self._lp = lp
         self._L = lp.load()
         zr = (C.c_int * (2 * len(zap)))(*[v for pair in zap for v in pair])
         self._s = C.c_void_p()
-        rc = self._L.pb_search_create(device, nchan, max_samples, fch1, foff, tsamp, dm_min, dm_max, dm_step,
-                                      boxcar_max, zr, len(zap), C.byref(self._s))
+        if dm_list is not None:
+            dl = np.ascontiguousarray(dm_list, np.float32)
+            rc = self._L.pb_search_create_list(device, nchan, max_samples, fch1, foff, tsamp,
+                                               dl.ctypes.data_as(C.POINTER(C.c_float)), dl.size, boxcar_max, zr, len(zap),
+                                               C.byref(self._s))
+        else:
+            rc = self._L.pb_search_create(device, nchan, max_samples, fch1, foff, tsamp, dm_min, dm_max, dm_step,
+                                          boxcar_max, zr, len(zap), C.byref(self._s))
         if rc != 0:
             raise lp.PbError("pb_search_create failed (%d): %s" % (rc, self._L.pb_search_last_error(None).decode()))
         ndm, nbox, md = C.c_int(), C.c_int(), C.c_int()
         self._L.pb_search_info(self._s, C.byref(ndm), C.byref(nbox), C.byref(md))
         self.ndm, self.nbox, self.max_delay = ndm.value, nbox.value, md.value
         self.nchan, self.tsamp = nchan, tsamp
-        self.dms = dm_min + dm_step * np.arange(self.ndm)
+        self.dms = dm_min + dm_step * np.arange(self.ndm) if dm_list is None else np.asarray(dm_list, np.float64)
 
     def close(self):
         if getattr(self, "_s", None):
@@ -201,3 +232,57 @@ def candidate_line(c):
     """One heimdall-format text line (columns of src/candidate.py:8-18); see candidates.py for the TCP leg."""
     import importlib
     return importlib.import_module((__package__ or "vlite-fast_amd") + ".candidates").candidate_line(c)
+
+
+def main(argv=None):
+    """heimdall's place in the chain for a SIGPROC file: `python -m vlite-fast_amd.search -f obs_kur.fil
+    -dm 2 1000 -boxcar_max 64 -nsamps_gulp 30720 -zap_chans 0 190 -zap_chans 3900 4096 -coincidencer vlite-nrl:27555`
+    (the flags of scripts/start_heimdall_single_antenna:21).  Prints heimdall-format candidate lines per gulp
+    and, with -coincidencer, sends them there."""
+    import argparse
+    sig = importlib.import_module(_pkg + ".sigproc")
+    ap = argparse.ArgumentParser(prog="search", prefix_chars="-")
+    ap.add_argument("-f", dest="fil", required=True)
+    ap.add_argument("-dm", nargs=2, type=float, default=list(HEIMDALL_DM))
+    ap.add_argument("-dm_tol", type=float, default=1.25)
+    ap.add_argument("-dm_step", type=float, default=0.0, help="> 0: linear grid instead of the tolerance-spaced list")
+    ap.add_argument("-boxcar_max", type=int, default=HEIMDALL_BOXCAR_MAX)
+    ap.add_argument("-nsamps_gulp", type=int, default=HEIMDALL_GULP)
+    ap.add_argument("-zap_chans", nargs=2, type=int, action="append", default=None)
+    ap.add_argument("-detect_thresh", type=float, default=6.0)
+    ap.add_argument("-baseline_length", type=float, default=2.0, help="seconds")
+    ap.add_argument("-beam", type=int, default=1)
+    ap.add_argument("-coincidencer", default=None)
+    ap.add_argument("-gpu_id", type=int, default=0)
+    a = ap.parse_args(argv)
+    with open(a.fil, "rb") as f:
+        hdr, off = sig.read_header(f.read(4096))
+    if hdr["nbits"] != 8 or hdr.get("nifs", 1) != 1:
+        raise SystemExit("search: 8-bit single-IF filterbanks only")
+    nchan, tsamp = hdr["nchans"], hdr["tsamp"]
+    zap = tuple(tuple(z) for z in a.zap_chans) if a.zap_chans else ()
+    dml = None if a.dm_step > 0 else dedisp_dm_list(a.dm[0], a.dm[1], tsamp, hdr["fch1"], hdr["foff"], nchan, a.dm_tol)
+    kw = dict(device=a.gpu_id, nchan=nchan, fch1=hdr["fch1"], foff=hdr["foff"], tsamp=tsamp, boxcar_max=a.boxcar_max, zap=zap)
+    s = Searcher(max_samples=a.nsamps_gulp + int(4.148808e3 * a.dm[1] * abs((hdr["fch1"] + (nchan - 1) * hdr["foff"]) ** -2
+                                                                       - hdr["fch1"] ** -2) / tsamp) + 64,
+                 dm_list=dml, dm_min=a.dm[0], dm_max=a.dm[1], dm_step=a.dm_step or 2.0, **kw)
+    s.set_baseline(int(a.baseline_length / tsamp))
+    import time as _time
+    utc = _time.strftime("%Y-%m-%d-%H:%M:%S", _time.gmtime(round((hdr.get("tstart", 40587.0) - 40587.0) * 86400.0)))
+    g = GulpSearch(s, threshold=a.detect_thresh, coincidencer=a.coincidencer, utc_start=utc, beam=a.beam)
+    ntot = 0
+    with open(a.fil, "rb") as f:
+        f.seek(off)
+        while True:
+            blk = np.frombuffer(f.read(a.nsamps_gulp * nchan), np.uint8)
+            if blk.size < nchan:
+                break
+            for c in g.push(blk[:blk.size // nchan * nchan].reshape(-1, nchan)):
+                print(candidate_line(c))
+                ntot += 1
+    s.close()
+    return ntot
+
+
+if __name__ == "__main__":
+    main()
