@@ -57,7 +57,22 @@ struct Detect2Args {
                                    // a detect workgroup fits beside two channeliser workgroups of the next batch)
 #define D2_THREADS 384
 #define D2_WAVE_A 0
-#define D2_WAVE_L 4
+#ifndef D2_WAVE_L
+#define D2_WAVE_L 5               // waves i and i+4 share a SIMD
+#endif
+
+#ifdef D2_STAMP
+// timing experiments (variant builds only): per wave of one workgroup, cycles spent working / waiting at the
+// step barrier; read back with pb_internal_d2_stamps
+__device__ unsigned long long g_d2_stamp[8][4];
+extern "C" int pb_internal_d2_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_d2_stamp), sizeof(g_d2_stamp));
+}
+#define D2_NOW() ((long long)__builtin_amdgcn_s_memtime())
+#else
+#define D2_NOW() 0ll
+#endif
 
 namespace {
 
@@ -68,10 +83,27 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 
 // LDS operations of this wave done, then the workgroup barrier.  (Not __syncthreads(): its release fence
 // may also drain vmcnt, i.e. the loader's DMA that must stay in flight across steps.)
-__device__ __forceinline__ void step_barrier()
+__device__ __forceinline__ void step_barrier_raw()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+
+#ifdef D2_STAMP
+struct StepClock {
+    long long work = 0, wait = 0, t = 0, extra = 0;
+};
+__device__ __forceinline__ void step_barrier_clk(StepClock &c)
+{
+    const long long t1 = D2_NOW();
+    step_barrier_raw();
+    const long long t2 = D2_NOW();
+    if (c.t) { c.work += t1 - c.t; c.wait += t2 - t1; }
+    c.t = t2;
+}
+#define step_barrier() step_barrier_clk(clk)
+#else
+#define step_barrier() step_barrier_raw()
+#endif
 
 template <int NBIT> __device__ __forceinline__ unsigned quantise(float acc)
 {
@@ -90,7 +122,7 @@ template <int NBIT> __device__ __forceinline__ unsigned quantise(float acc)
 // which phase-B wave (0..3) a wave is, or -1: digit = parity * 2 + half of the (group, channel) lane tasks
 __device__ __forceinline__ int b_index(int wave)
 {
-    return wave == 1 ? 0 : (wave == 2 ? 1 : (wave == 3 ? 2 : (wave == 5 ? 3 : -1)));
+    return wave == 1 ? 0 : (wave == 2 ? 1 : (wave == 3 ? 2 : (wave == 9 - D2_WAVE_L ? 3 : -1)));
 }
 
 // What a phase-B lane holds of its chunk between the two steps it spends on it
@@ -240,6 +272,9 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
     constexpr int LPC = T / 4;        // DMA instructions per chunk (4 rows of 64 floats each)
     const int nstep = nchunk + 2;     // step k: loader k + D, A chunk k, B chunks k-1 (first half) and k-2 (second half)
     const int bi = b_index(wave);
+#ifdef D2_STAMP
+    StepClock clk;
+#endif
 
     if (wave == D2_WAVE_L) {
         // ---- loader: lane -> (row in group of 4, pol, 4 channels)
@@ -266,7 +301,13 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
             if (cu.c < nchunk) {
                 issue(cu);                              // chunk k + D2_DEPTH
                 cu.next(cps);
+#ifdef D2_STAMP
+                const long long tw0 = D2_NOW();
+#endif
                 wait_vmcnt<(D2_DEPTH - 1) * LPC>();     // chunk k + 1 has landed
+#ifdef D2_STAMP
+                clk.extra += D2_NOW() - tw0;
+#endif
             } else {
                 wait_vmcnt<0>();
             }
@@ -408,6 +449,13 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
         step_barrier();
         for (int k = 0; k < nstep; ++k) step_barrier();
     }
+#ifdef D2_STAMP
+    if (blockIdx.x == 17 && blockIdx.y == 1 && blockIdx.z == 0 && lane == 0) {
+        g_d2_stamp[wave & 7][0] = (unsigned long long)clk.work;
+        g_d2_stamp[wave & 7][1] = (unsigned long long)clk.wait;
+        g_d2_stamp[wave & 7][2] = (unsigned long long)clk.extra;
+    }
+#endif
 }
 
 // MODE = rfi_mode: 0 raw stream only, 1 excised only, 2 both (blockIdx.y picks the stream)
