@@ -14,6 +14,9 @@
 // composed around the same fp32 FIR (bit-exact, RFI mode 0); the weight definition has no reference.
 #include "fft_lds.h"
 
+#ifndef PFB_DBG
+#define PFB_DBG 0     // timing experiments only: 1 no coefficient loads, 2 one tap only, 4 stage one row only
+#endif
 #define PFB_ROW_LDS 12528    // 12500 bytes + up to 12 of alignment slack, padded to 16
 #define PFB_HIST_STRIDE 12512
 
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
     // stage the four rows (16-byte loads of the aligned chunks that cover each row)
     unsigned off[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = (PFB_DBG & 4) ? 3 : 0; j < 4; ++j) {
         const int rr = grow - 3 + j;
         const uint8_t *base;
         size_t rbyte;
@@ -119,6 +122,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
         // the four taps of sample pair n are 32 contiguous bytes, and consecutive lanes take consecutive
         // n: two coalesced 16-byte loads per block r (taps 0,1 and 2,3) instead of four 8-byte ones
         auto coef2 = [&](int jj, int r) __attribute__((always_inline)) {
+            if (PFB_DBG & 1) { f4 one = {1.f, 1.f, 1.f, 1.f}; return one; }
             return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsF, tid * 32, (250 * r * 4 + jj) * 8, 0));
         };
         const unsigned m0 = kur ? mask[0] : 0u, m1 = kur ? mask[1] : 0u, m2 = kur ? mask[2] : 0u,
@@ -133,7 +137,8 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
                 const unsigned z = 0u - ((m >> r) & 1u);          // all ones when block r is flagged
                 return (raw & ~z) | (0x8080u & z);
             };
-            const unsigned w0 = pick(m0, s0[n]), w1 = pick(m1, s1[n]), w2 = pick(m2, s2[n]), w3 = pick(m3, s3[n]);
+            const unsigned w0 = pick(m0, s0[n]);
+            const unsigned w1 = (PFB_DBG & 2) ? w0 : pick(m1, s1[n]), w2 = (PFB_DBG & 2) ? w0 : pick(m2, s2[n]), w3 = (PFB_DBG & 2) ? w0 : pick(m3, s3[n]);
             // sum_j taps[j] * x_j, products then left-to-right adds (the order of k_channelize_f32),
             // re and im side by side in packed instructions
             const f4 c01 = coef2(0, r), c23 = coef2(2, r);
