@@ -12,6 +12,10 @@
                          // pass-2 arithmetic (bit 1) or between that arithmetic and its LDS stores (bit 2)
 #endif
 
+#ifndef FFT_STAMP
+#define FFT_STAMP(i)   // timing experiments: a variant build records the wave's clock at phase boundary i
+#endif
+
 namespace {
 constexpr float kW25[25][2] = FC_W25_INIT;
 constexpr float kW10[5][2] = FC_W10_INIT;
@@ -201,12 +205,14 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
         for (int r = 0; r < 25; ++r) buf[tid * 25 + r] = v[r];
     }
     __syncthreads();
+    FFT_STAMP(3);
     // pass 2: R = 25, Ns = 25
     if (tid < 250) {
 #pragma unroll
         for (int r = 0; r < 25; ++r) v[r] = buf[tid + 250 * r];
     }
     __syncthreads();
+    FFT_STAMP(4);
 #if !(FFT_PREFETCH & 1)
     load_t2();
 #endif
@@ -228,6 +234,7 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
         for (int r = 0; r < 25; ++r) buf[j0 + 25 * r] = v[r];
     }
     __syncthreads();
+    FFT_STAMP(5);
     // pass 3: R = 10, Ns = 625; butterflies j = tid, tid + 256, tid + 512, each in place on
     // buf[j + 625 r] (no barrier between its loads and its stores)
     f2 u[3][10];
@@ -256,6 +263,7 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
         }
     }
     __syncthreads();
+    FFT_STAMP(6);
 }
 
 // real-input split: X[k] = 0.5 (E + T[k] O), E = Z[k] + conj Z[M-k], O = Z[k] - conj Z[M-k]

@@ -27,13 +27,29 @@
 
 #include "pb_internal.h"
 
+#ifdef CH_STAMP
+// timing experiments (variant builds only): the clock at the phase boundaries of every workgroup's first
+// transform (+ its XCC id and flag mask); read back with pb_internal_ch_stamps
+#define CH_STAMP_MAXWG 40960
+__shared__ unsigned long long ch_ts[9];
+__device__ unsigned long long g_ch_stamp[CH_STAMP_MAXWG][13];
+extern "C" int pb_internal_ch_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ch_stamp), sizeof(g_ch_stamp));
+}
+#ifndef CH_STAMP_TID
+#define CH_STAMP_TID 0
+#endif
+#define FFT_STAMP(i) do { if (threadIdx.x == CH_STAMP_TID) ch_ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #include "fft_lds.h"
 
 struct ChanArgs {
     const uint8_t *in;      // [A][S][2][seg_samples]
     size_t in_ant_stride, seg_samples;
-    const uint8_t *flags;   // [A][S*R*25]
-    size_t flags_ant_stride;
+    const float *wrow;        // [A][S*R] row weights and
+    const uint32_t *rowmask;  // flag masks from k_kurtosis_row (bit r = block r flagged)
+    size_t wrow_ant_stride;
     float *Praw, *Pkur;     // [A][S][2][R][4096]
     size_t p_ant_stride;
     const float2 *tw2, *tw3, *post;
@@ -42,37 +58,52 @@ struct ChanArgs {
     int R, rfi_mode, inject_now;
 };
 
-// One transform of one (row, pol): ROLE 0 = raw spectrum (also fills the excised plane when the row
-// has no flagged block), ROLE 1 = excised spectrum (flagged blocks zeroed).
-template <int ROLE>
-__device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int tid, int seg, int row, int pol,
-                                                int ant, unsigned mask, float wrow, size_t prow)
+// The row's 12500 bytes go to LDS through 16-byte loads (narrow per-lane loads are bound by the address unit,
+// not by HBM: 2-byte loads move 128 B per wave instruction, these 1 KiB).  Rows are only 4-byte aligned, so the
+// aligned 16-byte chunks that cover the row are fetched (d_in is padded for the overhang): chunks tid, tid+256,
+// tid+512 always exist (782 or 783 in all), tid+768 for tid < 15.
+struct RowStage {
+    uint4 t0, t1, t2, t3;
+};
+__device__ __forceinline__ size_t row_byte(const ChanArgs &a, int seg, int row, int pol, int ant)
 {
-
-    // Stage the row's 12500 bytes in LDS with 16-byte loads (narrow per-lane loads are bound by
-    // the address unit, not by HBM: 2-byte loads move 128 B per wave instruction, these 1 KiB),
-    // then let every thread pick its 25 sample pairs out of LDS.  Rows are only 4-byte aligned,
-    // so load the aligned 16-byte chunks that cover the row (d_in is padded for the overhang).
-    const size_t rbyte = (size_t)ant * a.in_ant_stride + ((size_t)seg * 2 + pol) * a.seg_samples +
-                         (size_t)row * PB_NFFT;
-    const unsigned o = (unsigned)(rbyte & 15);
+    return (size_t)ant * a.in_ant_stride + ((size_t)seg * 2 + pol) * a.seg_samples + (size_t)row * PB_NFFT;
+}
+__device__ __forceinline__ void stage_request(const ChanArgs &a, int tid, int seg, int row, int pol, int ant, RowStage &st)
+{
+    const size_t rbyte = row_byte(a, seg, row, pol, ant);
+    const unsigned o = (unsigned)(rbyte & 15);   // offset of the row's first byte in its first chunk
     const uint4 *src16 = (const uint4 *)(a.in + (rbyte - o));
     const int nch = (int)((o + PB_NFFT + 15) >> 4);   // <= 783
+    st.t0 = src16[tid];
+    st.t1 = src16[tid + 256];
+    st.t2 = src16[tid + 512];
+    st.t3 = make_uint4(0u, 0u, 0u, 0u);
+    if (tid + 768 < nch) st.t3 = src16[tid + 768];
+}
+
+// One transform of one (row, pol): ROLE 0 = raw spectrum (also fills the excised plane when the row
+// has no flagged block), ROLE 1 = excised spectrum (flagged blocks zeroed).  The row's bytes have been
+// requested by stage_request; mask and wrow may still be in flight (ROLE 0 first needs them after the FFT).
+// next_row >= 0: the bytes of that row (of the same segment and pol) are requested into st as soon as the FFT is
+// done, so that their latency runs under this transform's spectrum step.
+template <int ROLE>
+__device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int tid, int seg, int row, int pol, int ant,
+                                                RowStage &st, unsigned mask, float wrow, size_t prow, int next_row)
+{
+    FFT_STAMP(0);
+    const unsigned o = (unsigned)(row_byte(a, seg, row, pol, ant) & 15);   // recomputed, not carried from the request
     {
-        // nch is 782 or 783: chunks tid, tid+256, tid+512 always exist, tid+768 for tid < 15
-        const uint4 t0 = src16[tid], t1 = src16[tid + 256], t2 = src16[tid + 512];
-        const bool has3 = tid + 768 < nch;
-        uint4 t3 = make_uint4(0u, 0u, 0u, 0u);
-        if (has3) t3 = src16[tid + 768];
         // a dropped-frame byte (0) means "no sample" = 0.0 = code 128 (convertarray :23-33): patch the
         // codes here, four per instruction, so that the conversion below is one fma per sample pair
         uint4 *stage = (uint4 *)buf;
-        stage[tid] = fix_zero_codes(t0);
-        stage[tid + 256] = fix_zero_codes(t1);
-        stage[tid + 512] = fix_zero_codes(t2);
-        if (has3) stage[tid + 768] = fix_zero_codes(t3);
+        stage[tid] = fix_zero_codes(st.t0);
+        stage[tid + 256] = fix_zero_codes(st.t1);
+        stage[tid + 512] = fix_zero_codes(st.t2);
+        if (tid + 768 < (int)((o + PB_NFFT + 15) >> 4)) stage[tid + 768] = fix_zero_codes(st.t3);
     }
     __syncthreads();
+    FFT_STAMP(1);
     f2 v[25];
     if (tid < 250) {
         const unsigned zmask = ROLE == 1 ? mask : 0u;
@@ -85,6 +116,7 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
         }
     }
     __syncthreads();   // all samples are in registers before pass 1 overwrites buf
+    FFT_STAMP(2);
     // The spectrum step's eight twiddle loads are requested from inside pass 3: one L2 latency for the
     // whole step instead of one per 1024-channel slice, and most of it hidden under pass 3 (the step was
     // 25-35 % of a workgroup's life, almost all of it waiting).
@@ -97,6 +129,7 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
         }
     };
     fft6250(v, buf, (const f2 *)a.tw2, (const f2 *)a.tw3, tid, load_tq);
+    if (next_row >= 0) stage_request(a, tid, seg, next_row, pol, ant, st);
 
     // FRB injection window of this row, per channel (inject_frb :361-380)
     const bool inject = a.frb.delays != nullptr && a.inject_now > 0;
@@ -138,58 +171,89 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
             *(float4 *)((ROLE == 1 ? P0 : P1) + c4) =
                 make_float4(pw[0] / wrow, pw[1] / wrow, pw[2] / wrow, pw[3] / wrow);
     }
+#ifdef CH_STAMP
+    if (ROLE == 0 && threadIdx.x == CH_STAMP_TID) {
+        ch_ts[7] = __builtin_amdgcn_s_memtime();
+        const unsigned wg = blockIdx.x + gridDim.x * blockIdx.y;
+        if (wg < CH_STAMP_MAXWG && blockIdx.z == 0) {
+            for (int i = 0; i < 8; ++i) g_ch_stamp[wg][i] = ch_ts[i];
+            g_ch_stamp[wg][8] = __builtin_amdgcn_s_getreg(20 | (3 << 11));   // HW_REG_XCC_ID[3:0]
+            g_ch_stamp[wg][9] = mask;
+            g_ch_stamp[wg][10] = __builtin_amdgcn_s_getreg(4 | (31 << 11));      // HW_REG_HW_ID
+            g_ch_stamp[wg][11] = __builtin_amdgcn_s_memrealtime();
+            g_ch_stamp[wg][12] = ch_ts[8];   // kernel entry
+        }
+    }
+#endif
 }
 
-// Three workgroups per CU (LDS 3 x 50 000 B, <= 168 VGPRs).  Measured (profiles/r01 notes):
+// Three workgroups per CU (LDS 3 x 50 000 B, <= 168 VGPRs).  A workgroup takes CH_ROWS consecutive rows of one
+// (segment, pol) and requests the bytes of its next transform (the same row again when it has flagged blocks,
+// else the next row) while the current one is in its spectrum step.  Measured (profiles/r02_notes.md, per-workgroup
+// clock stamps): the request-to-LDS latency is 3000 cycles of a 22 000-cycle transform and a workgroup hand-over
+// ~1500, yet 2 rows per workgroup are only 1-2 % faster than 1, and 8 or 16 are slower: the three co-resident
+// workgroups fill each other's waits, and longer runs of rows bring the workgroups of a CU into step.
+// Measured earlier (profiles/r01 notes):
 //  * capping residency at two to let a detect workgroup of the previous batch co-reside does not
 //    pay -- both kernels are bound by VALU issue, so side by side they only stretch each other;
-//  * persistent workgroups that prefetch the next row into registers are 12 % SLOWER than one
-//    workgroup per (row, pol): the hardware dispatcher's staggered starts overlap the workgroups'
-//    load, FFT and store phases better than a lock-step loop does.
+//  * fully persistent workgroups (768 for the whole launch) were 12 % SLOWER than one workgroup per (row, pol):
+//    the dispatcher's staggered starts overlap the workgroups' load, FFT and store phases better than a
+//    lock-step loop does.  Short runs of rows keep that staggering.
+#ifndef CH_ROWS
+#define CH_ROWS 2
+#endif
 __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
 {
     __shared__ f2 buf[M_HALF];
+    FFT_STAMP(8);
     int tid = threadIdx.x;
-    const int grow = blockIdx.x;  // seg * R + row
-    const int pol = blockIdx.y, ant = blockIdx.z;
-    const int seg = grow / a.R, row = grow % a.R;
+    // grid (ceil(R / CH_ROWS), nseg * 2, A): no division to find the rows
+    const int row0 = blockIdx.x * CH_ROWS, seg = blockIdx.y >> 1, pol = blockIdx.y & 1, ant = blockIdx.z;
+    const int nrow = min(CH_ROWS, a.R - row0);
 
-    unsigned mask = 0;
+    // The first row's bytes are requested first; the rows' flag masks and weights (written by the kurtosis kernel:
+    // lane i of every wave fetches the mask of row i, lane CH_ROWS + i its weight) follow, so that neither latency
+    // precedes the other (25 flag bytes fetched before any sample was requested cost 1.7 us per workgroup).
+    RowStage st;
+    stage_request(a, tid, seg, row0, pol, ant, st);
+    unsigned vmw = 0;
     if (a.rfi_mode) {
-        // every lane reads the 25 flag bytes of the row (uniform addresses -> scalar loads)
-        const uint8_t *f = a.flags + (size_t)ant * a.flags_ant_stride + (size_t)grow * PB_BLK_PER_FFT;
-#pragma unroll
-        for (int r = 0; r < PB_BLK_PER_FFT; ++r) mask |= (f[r] ? 1u : 0u) << r;
-        mask = __builtin_amdgcn_readfirstlane(mask);
+        const int l = tid & 63, i = l % CH_ROWS;
+        const size_t wi = (size_t)ant * a.wrow_ant_stride + (size_t)seg * a.R + row0 + i;
+        if (l < 2 * CH_ROWS && i < nrow) vmw = l < CH_ROWS ? a.rowmask[wi] : __builtin_bit_cast(unsigned, a.wrow[wi]);
     }
-    const bool all_bad = mask == 0x1ffffffu;
-    // passes of this workgroup: role 0 = raw spectrum (also fills the excised plane when the row has
-    // no flagged block), role 1 = excised spectrum (only when some block is flagged: 13 % of rows on
-    // clean noise).  One workgroup per (row, pol) does both, instead of launching a second grid of
-    // workgroups of which 87 % would exit at once.
-
-    // row weight exactly as apply_kurtosis accumulates it: one 500/12500 per unflagged block
-    float wrow = 0.f;
-    {
-        const float inc = (float)PB_NKURTO / PB_NFFT;
-        const int good = PB_BLK_PER_FFT - __popc(mask);
-        for (int i = 0; i < good; ++i) wrow = wrow + inc;
+#pragma unroll 1
+    for (int i = 0; i < nrow; ++i) {
+        const int row = row0 + i;
+        const int after = i + 1 < nrow ? row + 1 : -1;
+        // row weight exactly as apply_kurtosis accumulates it: one 500/12500 per unflagged block
+        const unsigned mask = __builtin_amdgcn_readlane(vmw, i);
+        const float wrow = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vmw, CH_ROWS + i));
+        const size_t prow = (size_t)ant * a.p_ant_stride + (((size_t)seg * 2 + pol) * a.R + row) * PB_NCHANOUT;
+        const bool all_bad = mask == 0x1ffffffu;
+        // transforms of this row: role 0 = raw spectrum (also fills the excised plane when the row has no
+        // flagged block), role 1 = excised spectrum (only when some block is flagged: 13 % of rows on clean
+        // noise), instead of launching a second grid of workgroups of which 87 % would exit at once.
+        const bool second = a.rfi_mode == 1 || (a.rfi_mode == 2 && mask != 0);
+        if (i) __syncthreads();   // the previous transform has finished reading buf
+        if (a.rfi_mode != 1) {
+            channelize_pass<0>(a, buf, tid, seg, row, pol, ant, st, mask, wrow, prow, second && !all_bad ? row : after);
+            if (!second) continue;
+        }
+        if (all_bad) {
+            // weight 0: the row's excised power is never used for its value (detect_and_normalize3
+            // :474-476 writes 0 and leaves the bandpass alone); +inf makes the detect kernel's clip test
+            // do exactly that without having to look at the weight
+            for (int c = tid; c < PB_NCHANOUT; c += 256) a.Pkur[prow + c] = __builtin_inff();
+            if (a.rfi_mode == 1 && after >= 0) stage_request(a, tid, seg, after, pol, ant, st);
+            continue;
+        }
+        if (a.rfi_mode == 2) {
+            __syncthreads();   // the raw pass has finished reading buf
+            asm volatile("" : "+v"(tid));   // no sharing of tid-derived addresses across the two passes
+        }
+        channelize_pass<1>(a, buf, tid, seg, row, pol, ant, st, mask, wrow, prow, after);
     }
-    const size_t prow = (size_t)ant * a.p_ant_stride + (((size_t)seg * 2 + pol) * a.R + row) * PB_NCHANOUT;
-    if (a.rfi_mode != 1) channelize_pass<0>(a, buf, tid, seg, row, pol, ant, mask, wrow, prow);
-    if (a.rfi_mode == 0 || (a.rfi_mode == 2 && mask == 0)) return;
-    if (all_bad) {
-        // weight 0: the row's excised power is never used for its value (detect_and_normalize3
-        // :474-476 writes 0 and leaves the bandpass alone); +inf makes the detect kernel's clip test
-        // do exactly that without having to look at the weight
-        for (int c = tid; c < PB_NCHANOUT; c += 256) a.Pkur[prow + c] = __builtin_inff();
-        return;
-    }
-    if (a.rfi_mode == 2) {
-        __syncthreads();   // the raw pass has finished reading buf
-        asm volatile("" : "+v"(tid));   // no sharing of tid-derived addresses across the two passes
-    }
-    channelize_pass<1>(a, buf, tid, seg, row, pol, ant, mask, wrow, prow);
 }
 
 static bool check_consts(std::string &why)
@@ -225,8 +289,9 @@ hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now)
     a.in = h->d_in;
     a.in_ant_stride = (size_t)h->S * 2 * h->seg_samples;
     a.seg_samples = h->seg_samples;
-    a.flags = h->d_flags;
-    a.flags_ant_stride = (size_t)h->S * h->nblk_seg;
+    a.wrow = h->d_wrow;
+    a.rowmask = pb_rowmask(h);
+    a.wrow_ant_stride = (size_t)h->S * h->R;
     a.Praw = h->d_Praw;
     a.Pkur = h->d_Pkur;
     a.p_ant_stride = (size_t)h->S * 2 * h->R * PB_NCHANOUT;
@@ -241,7 +306,7 @@ hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now)
     a.R = h->R;
     a.rfi_mode = h->cfg.rfi_mode;
     a.inject_now = inject_now;
-    dim3 grid((unsigned)(nseg * h->R), 2, (unsigned)h->A);
+    dim3 grid((unsigned)((h->R + CH_ROWS - 1) / CH_ROWS), (unsigned)(nseg * 2), (unsigned)h->A);
     k_channelize<<<grid, 256, 0, h->stream>>>(a);
     return hipGetLastError();
 }

@@ -29,6 +29,7 @@ struct PfbArgs {
     const uint8_t *hflags;   // [A][3][25]
     const uint8_t *hvalid;   // [A][3] history slot holds data
     const float *wrow;       // [A][S*R]  (already the PFB weights)
+    const uint32_t *rowmask; // [A][S*R]  flag masks of the rows (k_kurtosis_row), one scalar load instead of 25 bytes
     size_t wrow_ant_stride;
     const float2 *fir;       // [6250 n][4 taps] coefficient pairs of samples (2n, 2n+1) (FftTables::taps_n)
     float *Praw, *Pkur;
@@ -40,48 +41,24 @@ struct PfbArgs {
 
 __device__ __forceinline__ unsigned row_mask(const PfbArgs &a, int ant, int rr)
 {
-    // flags of the 25 blocks of row rr (rr < 0: history slot 3 + rr); uniform -> scalar loads
-    const uint8_t *f = rr >= 0 ? a.flags + (size_t)ant * a.flags_ant_stride + (size_t)rr * PB_BLK_PER_FFT
-                               : a.hflags + ((size_t)ant * 3 + (3 + rr)) * PB_BLK_PER_FFT;
+    // flags of the 25 blocks of row rr (rr < 0: history slot 3 + rr, the first three rows of a batch only)
+    if (rr >= 0) return __builtin_amdgcn_readfirstlane(a.rowmask[(size_t)ant * a.wrow_ant_stride + rr]);
+    const uint8_t *f = a.hflags + ((size_t)ant * 3 + (3 + rr)) * PB_BLK_PER_FFT;
     unsigned m = 0;
 #pragma unroll
     for (int r = 0; r < PB_BLK_PER_FFT; ++r) m |= (f[r] ? 1u : 0u) << r;
     return __builtin_amdgcn_readfirstlane(m);
 }
 
-__global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
+// One transform of one (row, pol): ROLE 0 = raw spectrum (also fills the excised plane when none of the four
+// contributing rows has a flagged block), ROLE 1 = excised spectrum.  The masks and the weight are scalar loads
+// requested at the top of the kernel; ROLE 0 first needs them after the FFT, so their latency and that of the
+// rows' bytes run side by side.
+template <int role>
+__device__ __forceinline__ void pfb_pass(const PfbArgs &a, uint8_t *lds, int tid, int grow, int seg, int row, int pol,
+                                         int ant, const unsigned (&mask)[4], unsigned differ, float w, size_t prow)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * PFB_ROW_LDS];   // 50 112 B, reused as the FFT buffer
     f2 *buf = (f2 *)lds;
-    const int tid = threadIdx.x;
-    const int grow = blockIdx.x;
-    const int pol = blockIdx.y & 1, ant = blockIdx.z;
-    const int role = a.rfi_mode == 2 ? (blockIdx.y >> 1) : (a.rfi_mode == 1 ? 1 : 0);
-    const int seg = grow / a.R, row = grow % a.R;
-
-    // zeroing masks of the four contributing rows.  A history slot that holds no data yet (start of
-    // the stream) is all zeros: nothing to excise there (its missing weight is booked by k_pfb_weights).
-    unsigned mask[4] = {0, 0, 0, 0};
-    unsigned differ = 0;
-    if (a.rfi_mode) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rr = grow - 3 + j;
-            const bool present = rr >= 0 || a.hvalid[ant * 3 + (3 + rr)] != 0;
-            mask[j] = present ? row_mask(a, ant, rr) : 0u;
-            differ |= mask[j];
-        }
-    }
-    differ = __builtin_amdgcn_readfirstlane(differ);
-    if (a.rfi_mode == 2 && role == 1 && differ == 0) return;
-
-    const float w = a.rfi_mode ? a.wrow[(size_t)ant * a.wrow_ant_stride + grow] : 1.f;
-    const size_t prow = (size_t)ant * a.p_ant_stride + (((size_t)seg * 2 + pol) * a.R + row) * PB_NCHANOUT;
-    if (role == 1 && w == 0.f) {
-        for (int c = tid; c < PB_NCHANOUT; c += 256) a.Pkur[prow + c] = __builtin_inff();
-        return;
-    }
-
     // stage the four rows (16-byte loads of the aligned chunks that cover each row)
     unsigned off[4];
 #pragma unroll
@@ -90,8 +67,12 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
         const uint8_t *base;
         size_t rbyte;
         if (rr >= 0) {
-            rbyte = (size_t)ant * a.in_ant_stride + ((size_t)(rr / a.R) * 2 + pol) * a.seg_samples +
-                    (size_t)(rr % a.R) * PB_NFFT;
+            int sj = seg, rj = row - 3 + j;   // (rr / R, rr % R) without the divisions
+            while (rj < 0) {
+                rj += a.R;
+                --sj;
+            }
+            rbyte = (size_t)ant * a.in_ant_stride + ((size_t)sj * 2 + pol) * a.seg_samples + (size_t)rj * PB_NFFT;
             base = a.in;
         } else {
             rbyte = (((size_t)ant * 2 + pol) * 3 + (3 + rr)) * PFB_HIST_STRIDE;
@@ -109,7 +90,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
 
     f2 v[25];
     if (tid < 250) {
-        const bool kur = role == 1;
+        constexpr bool kur = role == 1;
         const uint16_t *s0 = (const uint16_t *)(lds + 0 * PFB_ROW_LDS + off[0]);
         const uint16_t *s1 = (const uint16_t *)(lds + 1 * PFB_ROW_LDS + off[1]);
         const uint16_t *s2 = (const uint16_t *)(lds + 2 * PFB_ROW_LDS + off[2]);
@@ -198,6 +179,46 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
     }
 }
 
+// One workgroup per (row, pol) does both transforms (the second only when some contributing block is flagged: 43 %
+// of rows on clean noise), as k_channelize does: a second grid of workgroups for the excised spectra spent a load
+// latency each on finding out that 57 % of them had nothing to do.
+__global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * PFB_ROW_LDS];   // 50 112 B, reused as the FFT buffer
+    int tid = threadIdx.x;
+    // grid (R, nseg * 2, A): no division to find the row
+    const int row = blockIdx.x, seg = blockIdx.y >> 1, pol = blockIdx.y & 1, ant = blockIdx.z;
+    const int grow = seg * a.R + row;
+
+    // zeroing masks of the four contributing rows.  A history slot that holds no data yet (start of
+    // the stream) is all zeros: nothing to excise there (its missing weight is booked by k_pfb_weights).
+    unsigned mask[4] = {0, 0, 0, 0};
+    unsigned differ = 0;
+    const float w = a.rfi_mode ? a.wrow[(size_t)ant * a.wrow_ant_stride + grow] : 1.f;
+    if (a.rfi_mode) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rr = grow - 3 + j;
+            const bool present = rr >= 0 || a.hvalid[ant * 3 + (3 + rr)] != 0;
+            mask[j] = present ? row_mask(a, ant, rr) : 0u;
+            differ |= mask[j];
+        }
+    }
+    const size_t prow = (size_t)ant * a.p_ant_stride + (((size_t)seg * 2 + pol) * a.R + row) * PB_NCHANOUT;
+    if (a.rfi_mode != 1) pfb_pass<0>(a, lds, tid, grow, seg, row, pol, ant, mask, differ, w, prow);
+    if (a.rfi_mode == 0 || (a.rfi_mode == 2 && differ == 0)) return;
+    if (w == 0.f) {
+        for (int c = tid; c < PB_NCHANOUT; c += 256) a.Pkur[prow + c] = __builtin_inff();
+        return;
+    }
+    if (a.rfi_mode == 2) {
+        __syncthreads();   // the raw pass has finished reading the FFT buffer
+        asm volatile("" : "+v"(tid));   // no sharing of tid-derived addresses across the two passes
+    }
+    pfb_pass<1>(a, lds, tid, grow, seg, row, pol, ant, mask, differ, w, prow);
+}
+
+
 // row weights of the PFB mode (see the header comment); overwrites wrow[g]
 __global__ void k_pfb_weights(const uint8_t *__restrict__ flags, size_t flags_ant_stride,
                               const uint8_t *__restrict__ hflags, const float *__restrict__ tapE,
@@ -254,6 +275,7 @@ hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now)
     a.hflags = h->d_hist_flags;
     a.hvalid = h->d_hist_valid;
     a.wrow = h->d_wrow;
+    a.rowmask = pb_rowmask(h);
     a.wrow_ant_stride = (size_t)h->S * h->R;
     a.fir = h->ft.taps_n;
     a.Praw = h->d_Praw;
@@ -269,7 +291,7 @@ hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now)
     a.R = h->R;
     a.rfi_mode = h->cfg.rfi_mode;
     a.inject_now = inject_now;
-    dim3 grid((unsigned)nrows, h->cfg.rfi_mode == 2 ? 4 : 2, (unsigned)h->A);
+    dim3 grid((unsigned)h->R, (unsigned)(nseg * 2), (unsigned)h->A);
     k_channelize_pfb<<<grid, 256, 0, h->stream>>>(a);
     dim3 gh(3, 2, h->A);
     k_pfb_history<<<gh, 256, 0, h->stream>>>(h->d_in, a.in_ant_stride, h->seg_samples, h->d_flags, a.flags_ant_stride,

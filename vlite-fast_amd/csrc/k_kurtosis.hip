@@ -90,7 +90,7 @@ template <bool WRITE_F32>
 __global__ __launch_bounds__(256) void k_kurtosis_row(
     const uint8_t *__restrict__ in, size_t in_ant_stride, size_t seg_samples, int R,
     uint8_t *__restrict__ flags, size_t flags_ant_stride, float *__restrict__ wrow_out,
-    size_t wrow_ant_stride, float *__restrict__ stats, size_t nblk_cap,
+    uint32_t *__restrict__ rowmask_out, size_t wrow_ant_stride, float *__restrict__ stats, size_t nblk_cap,
     float *__restrict__ fraw, float *__restrict__ fkur, int write_raw, DagConsts dc, DagConsts dc_fb,
     float *__restrict__ stats_fb, size_t nrow_cap)
 {
@@ -249,9 +249,14 @@ __global__ __launch_bounds__(256) void k_kurtosis_row(
         // kur_weights[t] == kur_weights[t + FFTS_PER_SEG].
         const float inc = (float)PB_NKURTO / PB_NFFT;
         float w = 0.f;
-        for (int k = 0; k < PB_BLK_PER_FFT; ++k)
+        uint32_t m = 0;
+        for (int k = 0; k < PB_BLK_PER_FFT; ++k) {
             if (!sflag[k]) w = w + inc;
+            m |= (sflag[k] ? 1u : 0u) << k;
+        }
         wrow_out[(size_t)ant * wrow_ant_stride + grow] = w;
+        // the row's 25 flags as one word: the channeliser fetches it (and the weight) with one scalar load
+        rowmask_out[(size_t)ant * wrow_ant_stride + grow] = m;
     }
     if (WRITE_F32) {
 #pragma unroll
@@ -296,12 +301,12 @@ hipError_t launch_kurtosis_flag(pb_handle *h, int nseg, bool write_f32)
     float *stats_fb = h->d_stats ? h->d_stats + (size_t)h->A * 6 * nblk_cap : nullptr;
     if (write_f32)
         k_kurtosis_row<true><<<grid, 256, 0, h->stream>>>(
-            h->d_in, in_ant_stride, h->seg_samples, h->R, h->d_flags, nblk_cap, h->d_wrow, wrow_ant,
+            h->d_in, in_ant_stride, h->seg_samples, h->R, h->d_flags, nblk_cap, h->d_wrow, pb_rowmask(h), wrow_ant,
             h->d_stats, nblk_cap, h->d_fraw, h->d_fkur, h->cfg.rfi_mode == 2 ? 1 : 0, h->dag, h->dag_fb, stats_fb,
             nrow_cap);
     else
         k_kurtosis_row<false><<<grid, 256, 0, h->stream>>>(
-            h->d_in, in_ant_stride, h->seg_samples, h->R, h->d_flags, nblk_cap, h->d_wrow, wrow_ant,
+            h->d_in, in_ant_stride, h->seg_samples, h->R, h->d_flags, nblk_cap, h->d_wrow, pb_rowmask(h), wrow_ant,
             h->d_stats, nblk_cap, nullptr, nullptr, 0, h->dag, h->dag_fb, stats_fb, nrow_cap);
     return hipGetLastError();
 }

@@ -214,7 +214,8 @@ static int create_impl(pb_handle *h)
     HIPCHK(h, dmalloc(h, &h->d_in, in_elems + 64));   // + overhang of the channeliser's 16-byte row loads
     HIPCHK(h, dmalloc(h, &h->d_flags, A * S * h->nblk_seg));
     HIPCHK(h, hipMemset(h->d_flags, 0, A * S * h->nblk_seg));
-    HIPCHK(h, dmalloc(h, &h->d_wrow, A * S * R));
+    HIPCHK(h, dmalloc(h, &h->d_wrow, 2 * A * S * R));   // weights, then the rows' flag masks (pb_rowmask)
+    HIPCHK(h, hipMemset(h->d_wrow + A * S * R, 0, A * S * R * sizeof(uint32_t)));
     {
         // rfi_mode 0 never computes weights: every row counts fully
         std::vector<float> ones(A * S * R, 1.0f);

@@ -57,7 +57,7 @@ struct pb_handle {
     size_t h_idx_cap[8];
     hipEvent_t ev_idx[8];      // that copy has completed: the host may rewrite the index
     uint8_t *d_flags;      // [A][S*R*25]
-    float *d_wrow;         // [A][S*R]
+    float *d_wrow;         // [A][S*R] row weights, then [A][S*R] uint32 row flag masks (pb_rowmask)
     float *d_stats;        // debug: [A][3][2][S*R*25] pow,kur,dag
     float *d_fraw, *d_fkur;      // hipFFT path: f32 voltages, same indexing as d_in
     float2 *d_Xraw, *d_Xkur;     // hipFFT path: [A][S][2][R][6251]
@@ -107,6 +107,9 @@ struct pb_handle {
     std::vector<hipEvent_t> ev_pool;     // free events
     std::string err;
 };
+
+// row flag masks (bit r = kurtosis block r of the row is flagged), written by k_kurtosis_row behind the weights
+static inline uint32_t *pb_rowmask(pb_handle *h) { return (uint32_t *)(h->d_wrow + (size_t)h->A * h->S * h->R); }
 
 // ---- launchers (each enqueues on h->stream and returns a hipError_t) ----
 hipError_t launch_kurtosis_flag(pb_handle *h, int nseg, bool write_f32);
