@@ -78,16 +78,59 @@ __device__ __forceinline__ uint4 fix0(uint4 q) { return make_uint4(fix0(q.x), fi
 // r[lane] += r[lane + s] for s = 8, 4, 2, 1 inside a row of 16 lanes (DPP row_shl: lane i reads lane
 // i + s of its row); only lanes < s of the row hold meaningful sums afterwards, lane 0 the total --
 // the same additions in the same order as the reference's halving tree (kurtosis :60-94).
+// r[lane] += r[lane + 32] (lanes 0..31) and r[lane] += r[lane + 16] (lanes 0..15) with gfx950's lane-swap
+// instructions: one VALU issue each where __shfl_down goes through the LDS crossbar (ds_bpermute, ~100 cycles
+// of latency on a chain of 12-13 dependent block reductions per wave).  v_permlane32_swap a, b exchanges lanes
+// 32..63 of a with lanes 0..31 of b; v_permlane16_swap the odd 16-lane rows of a with the even rows of b.
+__device__ __forceinline__ float add_down32(float r)
+{
+    const unsigned u = __float_as_uint(r);
+    return r + __uint_as_float(__builtin_amdgcn_permlane32_swap(u, u, false, false)[1]);
+}
+__device__ __forceinline__ float add_down16(float r)
+{
+    const unsigned u = __float_as_uint(r);
+    return r + __uint_as_float(__builtin_amdgcn_permlane16_swap(u, u, false, false)[1]);
+}
+// two blocks at once: lanes 0..31 get x[l] + x[l + 32], lanes 32..63 get y[l - 32] + y[l]
+__device__ __forceinline__ float fold32(float x, float y)
+{
+    const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(p[0]) + __uint_as_float(p[1]);
+}
+// four blocks at once (x rows: A A B B, y rows: C C E E): rows (A, C, B, E), each row l < 16: v[l] + v[l + 16]
+__device__ __forceinline__ float fold16(float x, float y)
+{
+    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(p[0]) + __uint_as_float(p[1]);
+}
 template <int S> __device__ __forceinline__ float add_row_shl(float r)
 {
     const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x100 + S, 0xf, 0xf, true);
     return r + __int_as_float(t);
 }
 
+#ifdef KU_STAMP_ON
+// timing experiments (variant builds only): the clock at the phase boundaries of every workgroup
+__shared__ unsigned long long ku_ts[6];
+__device__ unsigned long long g_ku_stamp[20480][6];
+extern "C" int pb_internal_ku_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ku_stamp), sizeof(g_ku_stamp));
+}
+#define KU_STAMP(i) do { if (threadIdx.x == 0) ku_ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define KU_STAMP_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x < 20480 && blockIdx.y == 0) \
+    for (int i_ = 0; i_ < 6; ++i_) g_ku_stamp[blockIdx.x][i_] = ku_ts[i_]; } while (0)
+#else
+#define KU_STAMP(i)
+#define KU_STAMP_FLUSH()
+#endif
 #define ROW_CHUNKS 784   // 16-byte chunks covering a 12500-byte row at any 4-byte alignment
 
-template <bool WRITE_F32>
-__global__ __launch_bounds__(256) void k_kurtosis_row(
+// ROW_STATS: also the whole-row statistic K4 (debug_keep only; kept out of the production kernel, whose
+// registers it would otherwise dictate)
+template <bool WRITE_F32, bool ROW_STATS>
+__global__ __launch_bounds__(256, 6) void k_kurtosis_row(
     const uint8_t *__restrict__ in, size_t in_ant_stride, size_t seg_samples, int R,
     uint8_t *__restrict__ flags, size_t flags_ant_stride, float *__restrict__ wrow_out,
     uint32_t *__restrict__ rowmask_out, size_t wrow_ant_stride, float *__restrict__ stats, size_t nblk_cap,
@@ -95,6 +138,7 @@ __global__ __launch_bounds__(256) void k_kurtosis_row(
     float *__restrict__ stats_fb, size_t nrow_cap)
 {
     __shared__ uint4 sraw[2][ROW_CHUNKS];
+    KU_STAMP(0);
     __shared__ float s2[50], s4[50], sdag[50];
     __shared__ unsigned sflag[25];
     __shared__ float spow[50], skur[50], sfb[4];
@@ -127,11 +171,18 @@ __global__ __launch_bounds__(256) void k_kurtosis_row(
         if (h1) sraw[1][tid + 768] = fix0(b3);
     }
     __syncthreads();
+    KU_STAMP(1);
 
-    // each wave reduces blocks wave, wave+4, ...: leaves t = lane + 64 i hold (x[t]^2, x[t+250]^2),
-    // the pair side by side in packed-f32 instructions
-    for (int bi = wave; bi < 50; bi += 4) {
-        const int pol = bi / 25, blk = bi % 25;
+    // Each wave reduces 12 or 13 consecutive blocks (of the row's 2 x 25).  Leaves t = lane + 64 i hold
+    // (x[t]^2, x[t+250]^2), the pair side by side in packed-f32 instructions; the halving tree's levels 128 and
+    // 64 are additions in registers, 32..1 go across the wave: d[t] += d[t+s].  Four blocks share the
+    // cross-lane levels: one v_permlane32_swap + add folds the upper half of block A and of block B at once
+    // (A ends in lanes 0..31, B in 32..63), one v_permlane16_swap + add does level 16 of four blocks (one per
+    // 16-lane row), and the DPP levels 8..1 work inside rows anyway -- the same additions, on the same
+    // operands, as one block at a time (20 cross-lane instructions per four blocks instead of 120; the
+    // kernel is bound by vector issue in this loop).
+    auto leaves = [&](int bi, float &r2, float &r4) __attribute__((always_inline)) {
+        const int pol = bi >= 25 ? 1 : 0, blk = bi - 25 * pol;
         const uint8_t *sb = (const uint8_t *)sraw[pol] + (pol ? off1 : off0) + blk * PB_NKURTO;
         float d2[4], d4[4];
 #pragma unroll
@@ -150,13 +201,44 @@ __global__ __launch_bounds__(256) void k_kurtosis_row(
             d4[i] = in ? e4 : 0.f;
             d2[i] = in ? e2 : 0.f;
         }
-        // halving tree 128, 64 in registers, then 32..1 across the wave: d[t] += d[t+s]
-        float r2 = (d2[0] + d2[2]) + (d2[1] + d2[3]);
-        float r4 = (d4[0] + d4[2]) + (d4[1] + d4[3]);
-        r2 = r2 + __shfl_down(r2, 32);
-        r4 = r4 + __shfl_down(r4, 32);
-        r2 = r2 + __shfl_down(r2, 16);
-        r4 = r4 + __shfl_down(r4, 16);
+        r2 = (d2[0] + d2[2]) + (d2[1] + d2[3]);
+        r4 = (d4[0] + d4[2]) + (d4[1] + d4[3]);
+    };
+    // 13, 13, 12, 12 blocks
+    const int bi0 = wave * 12 + min(wave, 2), bi1 = bi0 + (wave < 2 ? 13 : 12);
+    int bi = bi0;
+    for (; bi + 4 <= bi1; bi += 4) {
+        float a2, a4, b2, b4, c2, c4, e2, e4;
+        leaves(bi, a2, a4);
+        leaves(bi + 1, b2, b4);
+        leaves(bi + 2, c2, c4);
+        leaves(bi + 3, e2, e4);
+        // level 32: x' = (x lanes 0..31, y lanes 0..31), y' = (x lanes 32..63, y lanes 32..63)
+        float ab2 = fold32(a2, b2), ab4 = fold32(a4, b4), ce2 = fold32(c2, e2), ce4 = fold32(c4, e4);
+        // level 16: rows (A, C, B, E)
+        float q2 = fold16(ab2, ce2), q4 = fold16(ab4, ce4);
+        q2 = add_row_shl<8>(q2);
+        q4 = add_row_shl<8>(q4);
+        q2 = add_row_shl<4>(q2);
+        q4 = add_row_shl<4>(q4);
+        q2 = add_row_shl<2>(q2);
+        q4 = add_row_shl<2>(q4);
+        q2 = add_row_shl<1>(q2);
+        q4 = add_row_shl<1>(q4);
+        if ((lane & 15) == 0) {
+            const int rowi = lane >> 4;                            // 0: A, 1: C, 2: B, 3: E
+            const int dst = bi + ((rowi & 1) << 1) + (rowi >> 1);
+            s2[dst] = q2;
+            s4[dst] = q4;
+        }
+    }
+    for (; bi < bi1; ++bi) {
+        float r2, r4;
+        leaves(bi, r2, r4);
+        r2 = add_down32(r2);
+        r4 = add_down32(r4);
+        r2 = add_down16(r2);
+        r4 = add_down16(r4);
         r2 = add_row_shl<8>(r2);
         r4 = add_row_shl<8>(r4);
         r2 = add_row_shl<4>(r2);
@@ -171,13 +253,14 @@ __global__ __launch_bounds__(256) void k_kurtosis_row(
         }
     }
     __syncthreads();
+    KU_STAMP(2);
     const size_t b0 = (size_t)grow * PB_BLK_PER_FFT;   // first block index of this row (per pol)
     if (tid < 50) {
         const int pol = tid / 25, blk = tid % 25;
         const float p = s2[tid] / PB_NKURTO;
         const float k = s4[tid] / PB_NKURTO / (p * p);
         sdag[tid] = dag_one(k, dc);
-        if (stats_fb) {
+        if (ROW_STATS && stats_fb) {
             spow[tid] = p;
             skur[tid] = k;
         }
@@ -188,11 +271,25 @@ __global__ __launch_bounds__(256) void k_kurtosis_row(
         }
     }
     __syncthreads();
+    KU_STAMP(3);
     if (tid < 25) {
         const float dmax = fmaxf(sdag[tid], sdag[25 + tid]);
         const bool bad = dmax > 3.0f;  // DAG_THRESH
         sflag[tid] = bad ? 1u : 0u;
         flags[(size_t)ant * flags_ant_stride + b0 + tid] = bad ? 1 : 0;
+        // the row's 25 flags as one word (lanes 0..24 of wave 0 are the only active ones here): the channeliser
+        // fetches it, and the weight, with one scalar load each
+        const uint32_t m = (uint32_t)__ballot(bad);
+        if (tid == 0) {
+            // kur_weights after apply_kurtosis (:292): one atomicAdd of 500/12500 per unflagged block;
+            // identical addends sum to the same float in any order.  Both pols share the flag, hence
+            // kur_weights[t] == kur_weights[t + FFTS_PER_SEG].
+            const float inc = (float)PB_NKURTO / PB_NFFT;
+            float w = 0.f;
+            for (int k = PB_BLK_PER_FFT - __popc(m); k > 0; --k) w = w + inc;
+            wrow_out[(size_t)ant * wrow_ant_stride + grow] = w;
+            rowmask_out[(size_t)ant * wrow_ant_stride + grow] = m;
+        }
         if (stats) {
             const size_t ab = (size_t)ant * 6 * nblk_cap;
             stats[ab + (2 * 2 + 0) * nblk_cap + b0 + tid] = dmax;
@@ -200,7 +297,8 @@ __global__ __launch_bounds__(256) void k_kurtosis_row(
         }
     }
     __syncthreads();
-    if (stats_fb) {
+    KU_STAMP(4);
+    if (ROW_STATS && stats_fb) {
         // K4: block_kurtosis + compute_dagostino2 (src/pb_kernels.cu:140-241), the statistic over the whole
         // FFT row.  No output depends on it (apply_kurtosis ignores dag_fb, :255-256), so it is only
         // computed when the statistics are kept (debug_keep): one lane per pol walks the reference's
@@ -243,21 +341,6 @@ __global__ __launch_bounds__(256) void k_kurtosis_row(
                 stats_fb[ab + 4 * nrow_cap + grow] = fmaxf(dag_one(sfb[2], dc_fb), dag_one(sfb[3], dc_fb));
         }
     }
-    if (tid == 0) {
-        // kur_weights after apply_kurtosis (:292): one atomicAdd of 500/12500 per unflagged block;
-        // identical addends sum to the same float in any order.  Both pols share the flag, hence
-        // kur_weights[t] == kur_weights[t + FFTS_PER_SEG].
-        const float inc = (float)PB_NKURTO / PB_NFFT;
-        float w = 0.f;
-        uint32_t m = 0;
-        for (int k = 0; k < PB_BLK_PER_FFT; ++k) {
-            if (!sflag[k]) w = w + inc;
-            m |= (sflag[k] ? 1u : 0u) << k;
-        }
-        wrow_out[(size_t)ant * wrow_ant_stride + grow] = w;
-        // the row's 25 flags as one word: the channeliser fetches it (and the weight) with one scalar load
-        rowmask_out[(size_t)ant * wrow_ant_stride + grow] = m;
-    }
     if (WRITE_F32) {
 #pragma unroll
         for (int pol = 0; pol < 2; ++pol) {
@@ -270,6 +353,8 @@ __global__ __launch_bounds__(256) void k_kurtosis_row(
             }
         }
     }
+    KU_STAMP(5);
+    KU_STAMP_FLUSH();
 }
 
 // plain unpack for rfi_mode 0 (convertarray only)
@@ -299,15 +384,17 @@ hipError_t launch_kurtosis_flag(pb_handle *h, int nseg, bool write_f32)
     // row statistics (K4) live behind the six per-block planes of every antenna
     const size_t nrow_cap = (size_t)h->S * h->R;
     float *stats_fb = h->d_stats ? h->d_stats + (size_t)h->A * 6 * nblk_cap : nullptr;
-    if (write_f32)
-        k_kurtosis_row<true><<<grid, 256, 0, h->stream>>>(
-            h->d_in, in_ant_stride, h->seg_samples, h->R, h->d_flags, nblk_cap, h->d_wrow, pb_rowmask(h), wrow_ant,
-            h->d_stats, nblk_cap, h->d_fraw, h->d_fkur, h->cfg.rfi_mode == 2 ? 1 : 0, h->dag, h->dag_fb, stats_fb,
-            nrow_cap);
-    else
-        k_kurtosis_row<false><<<grid, 256, 0, h->stream>>>(
-            h->d_in, in_ant_stride, h->seg_samples, h->R, h->d_flags, nblk_cap, h->d_wrow, pb_rowmask(h), wrow_ant,
-            h->d_stats, nblk_cap, nullptr, nullptr, 0, h->dag, h->dag_fb, stats_fb, nrow_cap);
+#define PB_KURT_LAUNCH(F32, FB)                                                                                   \
+    k_kurtosis_row<F32, FB><<<grid, 256, 0, h->stream>>>(                                                          \
+        h->d_in, in_ant_stride, h->seg_samples, h->R, h->d_flags, nblk_cap, h->d_wrow, pb_rowmask(h), wrow_ant,    \
+        h->d_stats, nblk_cap, F32 ? h->d_fraw : nullptr, F32 ? h->d_fkur : nullptr,                                \
+        F32 && h->cfg.rfi_mode == 2 ? 1 : 0, h->dag, h->dag_fb, stats_fb, nrow_cap)
+    if (write_f32) {
+        if (stats_fb) PB_KURT_LAUNCH(true, true); else PB_KURT_LAUNCH(true, false);
+    } else {
+        if (stats_fb) PB_KURT_LAUNCH(false, true); else PB_KURT_LAUNCH(false, false);
+    }
+#undef PB_KURT_LAUNCH
     return hipGetLastError();
 }
 
