@@ -117,3 +117,26 @@ def test_process_baseband_on_ring_keys(mock, tmp_path, monkeypatch):
     finally:
         for key in (0x40, 0x42, 0x46):
             mock.pb_dada_mock_destroy(key)
+
+
+def test_file_ring_parallel_readinto(tmp_path, monkeypatch):
+    """Large reads of a regular file are split over threads (pread at explicit offsets): same bytes, same
+    file position afterwards, short only at end of data; a FIFO keeps the sequential path."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    body = rng.integers(0, 256, 5 * 1024 * 1024 + 123, dtype=np.uint8)
+    path = tmp_path / "dump.vdif"
+    path.write_bytes(b"H" * dada.DADA_HDR_SIZE + body.tobytes())
+    monkeypatch.setattr(dada.FileRing, "_PAR_CHUNK", 256 * 1024)
+    ring = dada.FileRing(str(path))
+    assert ring.next_header() == b"H" * dada.DADA_HDR_SIZE
+    first = ring.read(1000)
+    assert first == body[:1000].tobytes()
+    buf = np.zeros(3 * 1024 * 1024, np.uint8)
+    assert ring.readinto(buf) == buf.size and ring._pool is not None
+    assert np.array_equal(buf, body[1000:1000 + buf.size])
+    rest = np.zeros(4 * 1024 * 1024, np.uint8)
+    got = ring.readinto(rest)
+    assert got == body.size - 1000 - buf.size
+    assert np.array_equal(rest[:got], body[1000 + buf.size:])
+    assert ring.readinto(rest) == 0

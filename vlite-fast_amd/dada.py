@@ -103,11 +103,14 @@ class FileRing(ReadRing):
         self._paths = [paths] if isinstance(paths, str) else list(paths)
         self._i = -1
         self._fp = None
+        self._pool = None
+        self._regular = None
 
     def next_header(self):
         if self._fp:
             self._fp.close()
             self._fp = None
+        self._regular = None
         self._i += 1
         if self._i >= len(self._paths):
             return None
@@ -133,10 +136,36 @@ class FileRing(ReadRing):
             got += len(more)
         return b"".join(parts)
 
+    # a single thread copies ~9 GB/s out of the page cache: one second of frames (258 MB) would cost 28 ms, a
+    # quarter of what the device needs for it; regular files are read by several threads at once
+    _PAR_CHUNK = 8 << 20
+    _PAR_THREADS = 8
+
     def readinto(self, arr):
         """Fill a uint8 numpy array (e.g. pinned staging) without an extra copy; returns the
         number of bytes read (short only at end of data)."""
         mv = memoryview(arr).cast("B")
+        fd = self._fp.fileno()
+        if len(mv) >= 2 * self._PAR_CHUNK and self._seekable():
+            pos = os.lseek(fd, 0, os.SEEK_CUR)
+            want = min(len(mv), max(0, os.fstat(fd).st_size - pos))
+            if want >= 2 * self._PAR_CHUNK:
+                if self._pool is None:
+                    from concurrent.futures import ThreadPoolExecutor
+                    self._pool = ThreadPoolExecutor(min(self._PAR_THREADS, os.cpu_count() or 1))
+
+                def piece(a):
+                    b, done = min(want, a + self._PAR_CHUNK), a
+                    while done < b:
+                        n = os.preadv(fd, [mv[done:b]], pos + done)
+                        if n <= 0:
+                            break
+                        done += n
+                    return done - a
+
+                got = sum(self._pool.map(piece, range(0, want, self._PAR_CHUNK)))
+                os.lseek(fd, pos + got, os.SEEK_SET)
+                return got
         got = 0
         while got < len(mv):
             n = self._fp.readinto(mv[got:])
@@ -144,6 +173,12 @@ class FileRing(ReadRing):
                 break
             got += n
         return got
+
+    def _seekable(self):
+        if self._regular is None:
+            import stat
+            self._regular = stat.S_ISREG(os.fstat(self._fp.fileno()).st_mode)
+        return self._regular
 
     def finish_observation(self):
         pass
