@@ -27,5 +27,5 @@ N = 20
 for _ in range(N):
     h.process(S)
     h.sync()
-print("taps %d, ms per launch alone:" % taps, {k: round(v[0], 4) for k, v in h.timers().items() if v[1]})
+print("taps %d, ms per launch alone:" % taps, {k: round(v[0] / v[1], 4) for k, v in h.timers().items() if v[1]})
 h.close()

@@ -277,6 +277,28 @@ __device__ __forceinline__ f2 rsplit(const f2 *buf, const f2 *__restrict__ post,
     return mk2(0.5f, 0.5f) * (E + P);
 }
 
+// Z[k] and Z[M - k] for k = k0 .. k0 + 3, k0 odd (the spectrum step's four channels of a thread; Z[M] = Z[0]),
+// through 16-byte LDS reads where the pair is aligned -- (k0+1, k0+2), (M-k0-1, M-k0), (M-k0-3, M-k0-2): 5 reads
+// instead of 8, and at the 32-byte lane stride of this step a 16-byte read meets half the bank conflicts of two
+// 8-byte ones.  buf must be 16-byte aligned.
+__device__ __forceinline__ void read_z_pairs(const f2 *buf, int k0, f2 (&za)[4], f2 (&zb)[4])
+{
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f2 za0 = buf[k0];
+    const f4v za12 = *(const f4v *)(buf + k0 + 1);
+    const f2 za3 = buf[k0 + 3 == M_HALF ? 0 : k0 + 3];
+    const f4v zb10 = *(const f4v *)(buf + (M_HALF - k0 - 1));
+    const f4v zb32 = *(const f4v *)(buf + (M_HALF - k0 - 3));
+    za[0] = za0;
+    za[1] = mk2(za12.x, za12.y);
+    za[2] = mk2(za12.z, za12.w);
+    za[3] = za3;
+    zb[0] = mk2(zb10.z, zb10.w);
+    zb[1] = mk2(zb10.x, zb10.y);
+    zb[2] = mk2(zb32.z, zb32.w);
+    zb[3] = mk2(zb32.x, zb32.y);
+}
+
 __device__ __forceinline__ float cvt_sample_c(unsigned u) { return u == 0 ? 0.0f : (float)u / 128 - 1; }
 
 // convertarray (src/pb_kernels.cu:23-33) on packed codes.  u / 128 and the subtraction of 1 are both

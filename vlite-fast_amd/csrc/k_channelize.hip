@@ -146,11 +146,14 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
         const float4 t01 = tq[i][0], t23 = tq[i][1];
         const f2 tw[4] = {mk2(t01.x, t01.y), mk2(t01.z, t01.w), mk2(t23.x, t23.y), mk2(t23.z, t23.w)};
         float pw[4];
+        const int k0 = PB_CHANMIN + c4;
+        f2 zas[4], zbs[4];
+        read_z_pairs(buf, k0, zas, zbs);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int k = PB_CHANMIN + c4 + q;
-            const f2 za = buf[k == M_HALF ? 0 : k];
-            const f2 zb = buf[M_HALF - k];
+            const int k = k0 + q;
+            const f2 za = zas[q];
+            const f2 zb = zbs[q];
             f2 E, O;
             addsub_conj(za, zb, E, O);
             const f2 Pq = cmul(O, tw[q]);
@@ -204,7 +207,7 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
 #endif
 __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
 {
-    __shared__ f2 buf[M_HALF];
+    __shared__ __attribute__((aligned(16))) f2 buf[M_HALF];
     FFT_STAMP(8);
     int tid = threadIdx.x;
     // grid (ceil(R / CH_ROWS), nseg * 2, A): no division to find the rows
