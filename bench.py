@@ -306,6 +306,42 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
     return res
 
 
+def alone_record(torch, lp, args, dev, local, taps, launches=10):
+    """The kernels of one second back to back on ONE stream (one buffer set): hipEvent time per launch with
+    nothing running beside them, and the dominant kernel's roofline fraction from that -- next to the figure
+    of the timed region, where the previous second's detect and copy-out share the CUs."""
+    S, A = args.seg_per_step, args.ant_per_gpu
+    backend = lp.FFT_LDS if args.backend == "lds" else lp.FFT_HIPFFT
+    h = lp.PbHandle(device=local, nant=A, nbit=args.nbit, npol=1, rfi_mode=args.rfi_mode, fft_backend=backend,
+                    rows_per_seg=ROWS, max_seg=S, nsets=1, taps=taps)
+    n = h.seg_samples
+    for a in range(A):
+        sec = synth_second(torch, dev, 42 + a, n, S, rfi_frac=args.rfi_frac)
+        torch.cuda.synchronize()
+        for s in range(S):
+            h.submit_planar_dev(a, s, sec[s][0].data_ptr(), sec[s][1].data_ptr(), n)
+        h.sync()
+        del sec
+    for _ in range(3):
+        h.process(S)
+        h.sync()
+    h.profile(True)
+    h.timers(reset=True)
+    for _ in range(launches):
+        h.process(S)
+        h.sync()
+    tm = h.timers(reset=True)
+    alg = algorithmic_bytes(args, h, n, 1, taps)
+    ms = {k: v[0] / v[1] for k, v in tm.items() if v[1] > 0}
+    dom = max((k for k in ms if k in alg), key=lambda k: ms[k])
+    per_launch = alg[dom] * S * A
+    achieved = per_launch / (ms[dom] * 1e-3) / 1e9
+    h.close()
+    return {"kernel": dom, "avg_launch_ms": round(ms[dom], 4), "achieved": round(achieved, 1),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "launches": launches,
+            "ms_per_launch": {k: round(v, 4) for k, v in ms.items()}}
+
+
 def search_record(lp, torch):
     """Downstream search (BASELINE config 5) on one heimdall-sized gulp, production flags of
     scripts/start_heimdall_single_antenna:21: 30 720 samples x 4096 channels of 8-bit codes, DM 2-1000 in
@@ -399,12 +435,18 @@ def main():
             "roofline": r["roofline"],
             "stage_ms_per_step": r["stage_ms_per_step"],
         }
+        if world == 1:
+            try:
+                out["roofline"]["alone"] = alone_record(torch, lp, args, dev, local, args.taps)
+            except Exception as e:
+                out["roofline"]["alone"] = {"error": str(e)}
         if world == 1 and not args.no_extras and args.taps == 1 and A == 1:
             nsub = max(20, args.steps // 3)
             t4 = run_chain(torch, dist, lp, args, dev, local, rank, world, 4, nsub, min(args.warmup, 5))
             out["taps4"] = {"ms_per_step": round(t4["ms_per_step"], 4), "value": round(t4["msamp"], 1), "unit": "Msamp/s",
                             "x_realtime_per_antenna": round(t4["msamp"] / 128.0, 1), "steps": nsub,
-                            "roofline": t4["roofline"], "stage_ms_per_step": t4["stage_ms_per_step"],
+                            "roofline": dict(t4["roofline"], alone=alone_record(torch, lp, args, dev, local, 4)),
+                            "stage_ms_per_step": t4["stage_ms_per_step"],
                             "note": "4-tap Hamming WOLA window (analysis/baseband.py:1207-1237) in the streaming path"}
             ing = run_chain(torch, dist, lp, args, dev, local, rank, world, 1, nsub, min(args.warmup, 5), ingest=True)
             gbs = 2 * (S * ing_frames(S) * 5032) / (ing["ms_per_step"] * 1e-3) / 1e9
