@@ -7,6 +7,9 @@
 
 #define M_HALF 6250
 
+#ifdef FFT_LEAN
+#define FFT_PREFETCH 0
+#endif
 #ifndef FFT_PREFETCH
 #define FFT_PREFETCH 5   // bit 0: pass-2 twiddles requested before pass 1; pass-3 twiddles requested before the
                          // pass-2 arithmetic (bit 1) or between that arithmetic and its LDS stores (bit 2)
@@ -235,6 +238,34 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
     }
     __syncthreads();
     FFT_STAMP(5);
+#ifdef FFT_LEAN
+    // pass 3, register-lean form (timing experiments: a 128-VGPR channeliser): one butterfly at a time, its
+    // twiddles requested just before it
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = tid + 256 * i;
+        if (j < 625) {
+            f2 u[10];
+            f2 t[9];
+#pragma unroll
+            for (int r = 1; r < 10; r += 2) {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                const f4 q = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs3, j * 80, (r - 1) * 8, 0));
+                t[r - 1] = mk2(q.x, q.y);
+                if (r < 9) t[r] = mk2(q.z, q.w);
+            }
+#pragma unroll
+            for (int r = 0; r < 10; ++r) u[r] = buf[j + 625 * r];
+            cmul4(u[1], u[2], u[3], u[4], t[0], t[1], t[2], t[3]);
+            cmul4(u[5], u[6], u[7], u[8], t[4], t[5], t[6], t[7]);
+            u[9] = cmul(u[9], t[8]);
+            dft10(u);
+#pragma unroll
+            for (int r = 0; r < 10; ++r) buf[j + 625 * r] = u[r];
+        }
+    }
+    in_pass3();
+#else
     // pass 3: R = 10, Ns = 625; butterflies j = tid, tid + 256, tid + 512, each in place on
     // buf[j + 625 r] (no barrier between its loads and its stores)
     f2 u[3][10];
@@ -246,7 +277,7 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
             for (int r = 0; r < 10; ++r) u[i][r] = buf[j + 625 * r];
         }
     }
-#if !(FFT_PREFETCH & 6)
+#if !(FFT_PREFETCH & 6) && !defined(FFT_LEAN)
     load_t3();
 #endif
 #pragma unroll
@@ -262,6 +293,7 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
             for (int r = 0; r < 10; ++r) buf[j + 625 * r] = u[i][r];
         }
     }
+#endif
     __syncthreads();
     FFT_STAMP(6);
 }

@@ -129,7 +129,9 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
         }
     };
     fft6250(v, buf, (const f2 *)a.tw2, (const f2 *)a.tw3, tid, load_tq);
+#ifndef FFT_LEAN
     if (next_row >= 0) stage_request(a, tid, seg, next_row, pol, ant, st);
+#endif
 
     // FRB injection window of this row, per channel (inject_frb :361-380)
     const bool inject = a.frb.delays != nullptr && a.inject_now > 0;
@@ -174,6 +176,9 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
             *(float4 *)((ROLE == 1 ? P0 : P1) + c4) =
                 make_float4(pw[0] / wrow, pw[1] / wrow, pw[2] / wrow, pw[3] / wrow);
     }
+#ifdef FFT_LEAN
+    if (next_row >= 0) stage_request(a, tid, seg, next_row, pol, ant, st);
+#endif
 #ifdef CH_STAMP
     if (ROLE == 0 && threadIdx.x == CH_STAMP_TID) {
         ch_ts[7] = __builtin_amdgcn_s_memtime();
@@ -205,9 +210,16 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
 #ifndef CH_ROWS
 #define CH_ROWS 2
 #endif
+#ifdef FFT_LEAN
+// (dynamic LDS: with a static 50-KB buffer the compiler sees three workgroups per CU and takes 168 registers)
+__global__ __launch_bounds__(256, 4) void k_channelize(ChanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) f2 buf[];
+#else
 __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
 {
     __shared__ __attribute__((aligned(16))) f2 buf[M_HALF];
+#endif
     FFT_STAMP(8);
     int tid = threadIdx.x;
     // grid (ceil(R / CH_ROWS), nseg * 2, A): no division to find the rows
@@ -310,7 +322,12 @@ hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now)
     a.rfi_mode = h->cfg.rfi_mode;
     a.inject_now = inject_now;
     dim3 grid((unsigned)((h->R + CH_ROWS - 1) / CH_ROWS), (unsigned)(nseg * 2), (unsigned)h->A);
+#ifdef FFT_LEAN
+    static const int lean_lds = getenv("PB_LEAN_LDS") ? atoi(getenv("PB_LEAN_LDS")) : M_HALF * 8;
+    k_channelize<<<grid, 256, lean_lds, h->stream>>>(a);
+#else
     k_channelize<<<grid, 256, 0, h->stream>>>(a);
+#endif
     return hipGetLastError();
 }
 
