@@ -234,6 +234,12 @@ int pb_search_peaks(pb_search *s, const void *codes, int codes_on_device, int ns
 /* device time of the last run's stages in ms: H2D, transpose, dedisperse, prefix + statistics, boxcar, D2H */
 int pb_search_timers(const pb_search *s, float *ms6);
 
+/* Page-locked host memory for the blocks handed to pb_submit_vdif(_at) (H2D copies from pageable memory are
+ * staged and synchronous); the reference allocates its 1-s host buffer the same way (cudaMallocHost,
+ * src/process_baseband.cu:579).  A host program above this ABI needs no HIP headers.  NULL on failure. */
+void *pb_host_alloc(size_t nbytes);
+void pb_host_free(void *p);
+
 const char *pb_version(void);
 
 #ifdef __cplusplus

@@ -39,6 +39,18 @@ static int fail(pb_handle *h, int code, const std::string &msg)
 
 extern "C" const char *pb_version(void) { return "pb_hip 0.1 (gfx950)"; }
 
+extern "C" void *pb_host_alloc(size_t nbytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, nbytes ? nbytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+extern "C" void pb_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 extern "C" void pb_config_default(pb_config *c)
 {
     memset(c, 0, sizeof *c);
