@@ -36,11 +36,12 @@ HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB
 
 
 def kernel_source_hash():
-    """Identifies the kernels a committed PMC profile was taken with: sha256 over the HIP sources."""
+    """Identifies the kernels a committed PMC profile was taken with: sha256 over the kernel sources (k_*.hip and
+    the headers they include; not the host side of the library, which moves no bytes on the device)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "vlite-fast_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
+        if (f.startswith("k_") and f.endswith(".hip")) or f in ("fft_lds.h", "fft_consts.h", "pb_internal.h"):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
