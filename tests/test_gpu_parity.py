@@ -182,6 +182,36 @@ def test_lds_backend_degenerate_inputs(oracle, case):
         assert _same_bits(got[m], ref[m])
 
 
+@pytest.mark.parametrize("case", ["dropped_segment", "saturated", "odd_rows_dead"])
+def test_lds_backend_degenerate_inputs_excised_only(oracle, case):
+    """RFI mode 1 (the excised stream alone): rows whose every block is flagged get no transform at all, and
+    the workgroup then has to request its next row itself -- at an even row (first of a workgroup's two), at
+    an odd one, and for whole segments."""
+    lp = libpb()
+    d = make_input(11, R, NSEG, rfi=False, dropped=False)
+    if case == "dropped_segment":
+        d[0] = 0
+        d[2, 0, :] = 0
+    elif case == "saturated":
+        d[0, 1] = 255
+        d[1, 0, 12500 * 2:12500 * 3] = 255           # row 2 (even) of segment 1, pol 0
+    else:
+        for r in (1, 3, 5):
+            d[1, :, 12500 * r:12500 * (r + 1)] = 255
+    g = _run_gpu(lp, d, lp.FFT_LDS, rfi_mode=1, npol=1, nbit=8)
+    res, bp_raw, _ = oracle_run(oracle, d, R, rfi_mode=1, npol=1, nbit=8)
+    refa = np.concatenate([compact_ave(r.ave_kur, R, 1) for r in res])
+    ga = g["ave_kur"]
+    assert np.array_equal(np.isnan(ga), np.isnan(refa))
+    ok = ~np.isnan(refa)
+    assert _same_bits(ga[ok], refa[ok])
+    assert np.array_equal(g["kur"], np.concatenate([r.codes_kur for r in res]))
+    ref = bp_raw.reshape(2, NCHAN)[:, 2155:]
+    got = g["bp"][1]
+    m = ~np.isnan(ref)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and _same_bits(got[m], ref[m])
+
+
 def test_channelizer_fft_matches_oracle_fft_bitwise(oracle):
     import synth
     lp = libpb()
