@@ -94,13 +94,22 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
     FFT_STAMP(0);
     const unsigned o = (unsigned)(row_byte(a, seg, row, pol, ant) & 15);   // recomputed, not carried from the request
     {
-        // a dropped-frame byte (0) means "no sample" = 0.0 = code 128 (convertarray :23-33): patch the
-        // codes here, four per instruction, so that the conversion below is one fma per sample pair
+        // a dropped-frame byte (0) means "no sample" = 0.0 = code 128 (convertarray :23-33), so that the
+        // conversion below is one fma per sample pair.  The kurtosis kernel has already patched such codes in
+        // the input buffer; only RFI mode 0, which has no kurtosis pass, does it here (four per instruction).
         uint4 *stage = (uint4 *)buf;
-        stage[tid] = fix_zero_codes(st.t0);
-        stage[tid + 256] = fix_zero_codes(st.t1);
-        stage[tid + 512] = fix_zero_codes(st.t2);
-        if (tid + 768 < (int)((o + PB_NFFT + 15) >> 4)) stage[tid + 768] = fix_zero_codes(st.t3);
+        const bool last = tid + 768 < (int)((o + PB_NFFT + 15) >> 4);
+        if (a.rfi_mode == 0) {
+            stage[tid] = fix_zero_codes(st.t0);
+            stage[tid + 256] = fix_zero_codes(st.t1);
+            stage[tid + 512] = fix_zero_codes(st.t2);
+            if (last) stage[tid + 768] = fix_zero_codes(st.t3);
+        } else {
+            stage[tid] = st.t0;
+            stage[tid + 256] = st.t1;
+            stage[tid + 512] = st.t2;
+            if (last) stage[tid + 768] = st.t3;
+        }
     }
     __syncthreads();
     FFT_STAMP(1);

@@ -83,8 +83,13 @@ __device__ __forceinline__ void pfb_pass(const PfbArgs &a, uint8_t *lds, int tid
         const uint4 *src16 = (const uint4 *)(base + (rbyte - o));
         const int nch = (int)((o + PB_NFFT + 15) >> 4);
         uint4 *dst = (uint4 *)(lds + j * PFB_ROW_LDS);
-        // code 0 ("no sample") becomes code 128 = 0.0 here, four bytes per instruction (fft_lds.h)
-        for (int i = tid; i < nch; i += 256) dst[i] = fix_zero_codes(src16[i]);
+        // code 0 ("no sample") is code 128 = 0.0: the kurtosis kernel has patched the input buffer; history rows
+        // (zero-filled before the stream starts) and RFI mode 0 (no kurtosis pass) are patched here, four bytes
+        // per instruction (fft_lds.h)
+        if (a.rfi_mode == 0 || rr < 0)
+            for (int i = tid; i < nch; i += 256) dst[i] = fix_zero_codes(src16[i]);
+        else
+            for (int i = tid; i < nch; i += 256) dst[i] = src16[i];
     }
     __syncthreads();
 

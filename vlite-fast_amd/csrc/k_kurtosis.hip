@@ -131,7 +131,7 @@ extern "C" int pb_internal_ku_stamps(unsigned long long *out)
 // registers it would otherwise dictate)
 template <bool WRITE_F32, bool ROW_STATS>
 __global__ __launch_bounds__(256, 6) void k_kurtosis_row(
-    const uint8_t *__restrict__ in, size_t in_ant_stride, size_t seg_samples, int R,
+    uint8_t *in, size_t in_ant_stride, size_t seg_samples, int R,
     uint8_t *__restrict__ flags, size_t flags_ant_stride, float *__restrict__ wrow_out,
     uint32_t *__restrict__ rowmask_out, size_t wrow_ant_stride, float *__restrict__ stats, size_t nblk_cap,
     float *__restrict__ fraw, float *__restrict__ fkur, int write_raw, DagConsts dc, DagConsts dc_fb,
@@ -164,11 +164,19 @@ __global__ __launch_bounds__(256, 6) void k_kurtosis_row(
         if (h0) a3 = s0[tid + 768];
         if (h1) b3 = s1[tid + 768];
         // code 0 ("no sample" -> 0.0, convertarray :23-33) is rewritten to code 128 (= 0.0) four bytes
-        // per instruction, so that the conversion below is one fma per pair: u/128 - 1 is exact
-        sraw[0][tid] = fix0(a0); sraw[0][tid + 256] = fix0(a1); sraw[0][tid + 512] = fix0(a2);
-        sraw[1][tid] = fix0(b0); sraw[1][tid + 256] = fix0(b1); sraw[1][tid + 512] = fix0(b2);
-        if (h0) sraw[0][tid + 768] = fix0(a3);
-        if (h1) sraw[1][tid + 768] = fix0(b3);
+        // per instruction, so that the conversion below is one fma per pair: u/128 - 1 is exact.  A chunk
+        // that held such a code also goes back to the input buffer patched (rare: dropped frames only), so
+        // that the channelisers -- which read every byte again, the PFB one four times -- need not repeat
+        // this.  Neighbouring rows share their boundary chunks: both write the same bytes.
+        auto stage = [&](uint4 *dst, const uint4 *src, int i, uint4 q) __attribute__((always_inline)) {
+            const uint4 f = fix0(q);
+            dst[i] = f;
+            if ((f.x ^ q.x) | (f.y ^ q.y) | (f.z ^ q.z) | (f.w ^ q.w)) ((uint4 *)src)[i] = f;
+        };
+        stage(sraw[0], s0, tid, a0); stage(sraw[0], s0, tid + 256, a1); stage(sraw[0], s0, tid + 512, a2);
+        stage(sraw[1], s1, tid, b0); stage(sraw[1], s1, tid + 256, b1); stage(sraw[1], s1, tid + 512, b2);
+        if (h0) stage(sraw[0], s0, tid + 768, a3);
+        if (h1) stage(sraw[1], s1, tid + 768, b3);
     }
     __syncthreads();
     KU_STAMP(1);
