@@ -82,6 +82,20 @@ __device__ __forceinline__ void stage_request(const ChanArgs &a, int tid, int se
     if (tid + 768 < nch) st.t3 = src16[tid + 768];
 }
 
+// x / (1 + 2^-23), the division of a row without flags (87 % of rows on clean noise), on the bits: the quotient
+// is the first or the second float below x -- the second when x's mantissa field m is 0 or >= 0x400002
+// (m 2^-23 >= 1.5 + ...: the exact quotient m (1 - 2^-23 + 2^-46 - ...) lies below the midpoint) -- checked
+// against the IEEE division for every positive normal binary32 from 0x00800002 up (tools/check_div_full_weight.c);
+// smaller values, zeros and non-finite ones take the division.  4 instructions instead of 11.
+__device__ __forceinline__ float div_full_weight(float x)
+{
+    const unsigned b = __builtin_bit_cast(unsigned, x);
+    const unsigned m1 = (b & 0x7fffffu) - 1u;
+    const float fast = __builtin_bit_cast(float, b - (m1 >= 0x400001u ? 2u : 1u));
+    if (__builtin_expect(b - 0x00800002u >= 0x7f800000u - 0x00800002u, 0)) return x / 1.00000011920928955078125f;
+    return fast;
+}
+
 // One transform of one (row, pol): ROLE 0 = raw spectrum (also fills the excised plane when the row
 // has no flagged block), ROLE 1 = excised spectrum (flagged blocks zeroed).  The row's bytes have been
 // requested by stage_request; mask and wrow may still be in flight (ROLE 0 first needs them after the FFT).
@@ -146,6 +160,8 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
     const bool inject = a.frb.delays != nullptr && a.inject_now > 0;
     const int since = inject ? (a.inject_now - 1 + seg) * a.R : 0;
     const bool also_kur = a.rfi_mode == 2 && ROLE == 0 && mask == 0;
+    // the weight of a row without flags: 25 x 0.04f summed left to right = 1 + 2^-23
+    const bool full_w = __builtin_bit_cast(unsigned, wrow) == 0x3f800001u;
     float *P0 = (ROLE == 1 ? a.Pkur : a.Praw) + prow;
     float *P1 = a.Pkur + prow;
     // four consecutive channels per thread: 16-byte twiddle loads and 16-byte power stores (one
@@ -181,9 +197,12 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
         // the excised plane carries pow / w (detect_and_normalize3 :452,:481), so that the
         // serial bandpass recurrence downstream has no division in it
         if (ROLE == 0) *(float4 *)(P0 + c4) = make_float4(pw[0], pw[1], pw[2], pw[3]);
-        if (ROLE == 1 || also_kur)
-            *(float4 *)((ROLE == 1 ? P0 : P1) + c4) =
-                make_float4(pw[0] / wrow, pw[1] / wrow, pw[2] / wrow, pw[3] / wrow);
+        if (ROLE == 1)
+            *(float4 *)(P0 + c4) = make_float4(pw[0] / wrow, pw[1] / wrow, pw[2] / wrow, pw[3] / wrow);
+        else if (also_kur)
+            *(float4 *)(P1 + c4) = full_w ? make_float4(div_full_weight(pw[0]), div_full_weight(pw[1]),
+                                                        div_full_weight(pw[2]), div_full_weight(pw[3]))
+                                          : make_float4(pw[0] / wrow, pw[1] / wrow, pw[2] / wrow, pw[3] / wrow);
     }
 #ifdef FFT_LEAN
     if (next_row >= 0) stage_request(a, tid, seg, next_row, pol, ant, st);
