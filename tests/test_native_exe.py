@@ -187,3 +187,29 @@ def test_ring_keys_reach_the_shim(tmp_path):
     subprocess.run(["gcc", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-o", so, src], check=True)
     r = _run(["-k", "40", "-b", "8", "--logdir", str(tmp_path), "-o", "--no-control"], env=dict(os.environ, PB_DADA_LIB=so))
     assert r.returncode == 1 and b"could not connect to input ring 40" in r.stdout and b"lacks symbols" not in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rfi_mode,nbit,npol", [(0, 8, 1), (1, 4, 1), (2, 2, 2)])
+def test_native_and_python_hosts_agree_in_other_modes(tmp_path, rfi_mode, nbit, npol):
+    from helpers import make_input
+    pbmod = importlib.import_module("vlite-fast_amd.process_baseband")
+    data = make_input(23, R, 4 * SEG)
+    dump = str(tmp_path / "obs.uw")
+    _dump(dump, data)
+    got = {}
+    for who in ("py", "cxx"):
+        d = tmp_path / who
+        d.mkdir()
+        argv = ["-w", "2", "-b", str(nbit), "-P", str(npol), "-r", str(rfi_mode), "--replay", dump, "--datadir", str(d),
+                "--logdir", str(d / "logs"), "--no-control", "--rows-per-seg", str(R), "--co-sink", str(d / "co.bin")]
+        if who == "py":
+            assert pbmod.run(pbmod.build_parser().parse_args(argv)) == 0
+        else:
+            r = _run(argv)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+        got[who] = {p.name: p.read_bytes() for p in sorted(d.glob("*.fil"))}
+        got[who]["co"] = (d / "co.bin").read_bytes()[4096:]
+    assert list(got["py"]) == list(got["cxx"]) and len(got["py"]) == (3 if rfi_mode == 2 else 2)
+    for n in got["py"]:
+        assert got["py"][n] == got["cxx"][n] and len(got["py"][n]) > 1000, n
