@@ -196,8 +196,15 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4 * PFB_ROW_LDS];   // 50 112 B, reused as the FFT buffer
     int tid = threadIdx.x;
-    // grid (R, nseg * 2, A): no division to find the row
-    const int row = blockIdx.x, seg = blockIdx.y >> 1, pol = blockIdx.y & 1, ant = blockIdx.z;
+    // grid (R, nseg * 2, A): no division to find the row.  Workgroups go to the 8 XCDs in turn, and an input row
+    // is read by the workgroups of four consecutive output rows: give every XCD a contiguous eighth of the
+    // segment's rows, so that three of those four reads hit its own L2 (R is a multiple of 8).
+#ifndef PFB_NO_XCD_MAP
+    const int row = (int)(blockIdx.x & 7) * (a.R >> 3) + (int)(blockIdx.x >> 3);
+#else
+    const int row = blockIdx.x;
+#endif
+    const int seg = blockIdx.y >> 1, pol = blockIdx.y & 1, ant = blockIdx.z;
     const int grow = seg * a.R + row;
 
     // zeroing masks of the four contributing rows.  A history slot that holds no data yet (start of
