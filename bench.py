@@ -179,15 +179,17 @@ def algorithmic_bytes(args, h, n, world, taps):
     return alg
 
 
-def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmup, ingest=False):
+def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmup, ingest=False, coadd=None):
     """One timed run of `steps` steps.  ingest: every second arrives as VDIF frames from page-locked host
     memory (pb_submit_vdif), otherwise the samples are resident in HBM."""
     S, A = args.seg_per_step, args.ant_per_gpu
+    if coadd is None:
+        coadd = world > 1        # the incoherent sum (local sum -> reduce -> requantise on the root) is part of the step
     backend = lp.FFT_LDS if args.backend == "lds" else lp.FFT_HIPFFT
     NSETS = args.nsets   # 2 = double-buffered batches: the D2H of second k and the host's collection of it overlap
                          # the kernels of second k+1
     h = lp.PbHandle(device=local, nant=A, nbit=args.nbit, npol=1, rfi_mode=args.rfi_mode,
-                    fft_backend=backend, rows_per_seg=ROWS, max_seg=S, keep_ave=(world > 1), nsets=NSETS, taps=taps)
+                    fft_backend=backend, rows_per_seg=ROWS, max_seg=S, keep_ave=coadd, nsets=NSETS, taps=taps)
     n = h.seg_samples
     blocks = None
     for a in range(A):
@@ -210,10 +212,18 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
                     h.submit_planar_dev(a, s, sec[s][0].data_ptr(), sec[s][1].data_ptr(), n)
             h.sync()
         del sec
-    d_sum = torch.zeros(S * h.ave_per_seg, dtype=torch.float32, device=dev) if world > 1 else None
+    d_sum = torch.zeros(S * h.ave_per_seg, dtype=torch.float32, device=dev) if coadd else None
+    d_sums = None
+    if coadd and A == 1 and args.backend == "lds":
+        # one antenna per GPU: detect writes the plane to be reduced straight into a buffer of ours, one per
+        # buffer set, and the local sum needs no kernel (pb_set_coadd_target)
+        d_sums = [torch.zeros(S * h.ave_per_seg, dtype=torch.float32, device=dev) for _ in range(NSETS)]
+        for st in range(NSETS):
+            h.select_set(st)
+            h.set_coadd_target(d_sums[st].data_ptr())
     nant_total = world * A
     nstream_out = (0, 1) if args.rfi_mode == 2 else ((0,) if args.rfi_mode == 0 else (1,))
-    state = {"k": 0, "sink": 0}
+    state = {"k": 0, "sink": 0, "coadds": 0}
 
     def collect(k):
         """filterbank bytes of batch k on the host (pinned mirror filled by the async D2H that
@@ -225,7 +235,7 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
                 state["sink"] += int(v[0]) + int(v[-1])
 
     ts = None
-    if world > 1:
+    if coadd:
         # The incoherent sum has a stream of its own: local sum -> RCCL reduce -> requantise of batch k
         # are ordered on it by the device (the library makes it wait for detect of batch k with an
         # event) and run beside the kernels of batch k+1; no host synchronisation inside a step.
@@ -233,34 +243,49 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
         h.sync()
         h.set_coadd_stream(ts.cuda_stream)
 
+    def finish_batch(j):
+        """Batch j is done on the device once its filterbank bytes are here (collect waits for them), so its
+        incoherent-sum leg -- local sum (nothing to launch with a coadd target), RCCL reduce, requantisation on
+        the root -- is queued on the coadd stream without a device-side wait for detect, one step behind the
+        batch itself, and runs beside the kernels of the batches after it."""
+        collect(j)                                    # (selects buffer set j mod NSETS)
+        parts = int(os.environ.get("PB_COADD_PARTS", "7"))     # timing experiments: 1 local sum, 2 reduce, 4 finish
+        if coadd and parts:
+            ds = d_sums[j % NSETS] if d_sums is not None else d_sum
+            with torch.cuda.stream(ts):
+                if parts & 1:
+                    h.coadd_local(S, ds.data_ptr())
+                if not parts & 2:
+                    pass
+                elif args.dist_backend == "nccl":
+                    dist.reduce(ds, dst=0, op=dist.ReduceOp.SUM)
+                else:                     # gloo rehearsal: through host memory
+                    ts.synchronize()
+                    t = ds.cpu()
+                    dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+                    ds.copy_(t)
+                if rank == 0 and parts & 4:
+                    h.coadd_finish(S, ds.data_ptr(), nant_total, blocking=False)
+                if d_sums is not None:
+                    h.coadd_release()
+            if rank == 0 and parts & 4 and state["coadds"]:
+                v = h.coadd_view(S, age=1)            # coadded bytes of the batch before
+                state["sink"] += int(v[0])
+            state["coadds"] += 1
+
     def step():
         k = state["k"]
         h.select_set(k % NSETS)
         if ingest:
             h.submit_vdif(0, 0, blocks[k % len(blocks)].numpy(), second=3600, frame0=0)
         h.process(S)
-        if world > 1:
-            with torch.cuda.stream(ts):
-                h.coadd_local(S, d_sum.data_ptr())
-                if args.dist_backend == "nccl":
-                    dist.reduce(d_sum, dst=0, op=dist.ReduceOp.SUM)
-                else:                     # gloo rehearsal: through host memory
-                    ts.synchronize()
-                    t = d_sum.cpu()
-                    dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
-                    d_sum.copy_(t)
-                if rank == 0:
-                    h.coadd_finish(S, d_sum.data_ptr(), nant_total, blocking=False)
         if k >= NSETS - 1:
-            collect(k - (NSETS - 1))
-            if world > 1 and rank == 0:
-                v = h.coadd_view(S, age=1)            # coadded bytes of the previous batch
-                state["sink"] += int(v[0])
+            finish_batch(k - (NSETS - 1))
         state["k"] = k + 1
 
     def drain():
         for kk in range(max(0, state["k"] - (NSETS - 1)), state["k"]):
-            collect(kk)
+            finish_batch(kk)
         state["k"] = 0
 
     for _ in range(warmup):
@@ -385,6 +410,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the taps4 / ingest / search sub-records")
+    ap.add_argument("--coadd-selftest", action="store_true",
+                    help="N = 1 only: print the step with the incoherent-sum leg of the N > 1 path switched on "
+                         "(fp32 planes kept, local sum, RCCL reduce in a one-rank group, requantisation) instead of the bench line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -412,6 +440,18 @@ def main():
 
     lp = importlib.import_module("vlite-fast_amd.libpb")
     S, A = args.seg_per_step, args.ant_per_gpu
+    if args.coadd_selftest and world == 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        plain = run_chain(torch, dist, lp, args, dev, local, 0, 1, args.taps, args.steps, args.warmup, coadd=False)
+        withc = run_chain(torch, dist, lp, args, dev, local, 0, 1, args.taps, args.steps, args.warmup, coadd=True)
+        print(json.dumps({"coadd_selftest": {"ms_per_step_plain": round(plain["ms_per_step"], 4),
+                                             "ms_per_step_with_coadd_leg": round(withc["ms_per_step"], 4),
+                                             "stage_ms_per_step": withc["stage_ms_per_step"]}}))
+        dist.destroy_process_group()
+        return
     r = run_chain(torch, dist, lp, args, dev, local, rank, world, args.taps, args.steps, args.warmup)
 
     if rank == 0:

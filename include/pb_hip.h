@@ -184,6 +184,15 @@ int pb_output_dev(pb_handle *h, int ant, int stream, void **codes, void **ave);
  * RCCL reduce of d_sum done by the host (torch.distributed); then on the root:
  * codes = sel_and_dig(d_sum / sqrt(nant_total)). */
 int pb_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate);
+/* One antenna per handle (nant = 1, the sharding of BASELINE configs[3] at one antenna per GPU): the plane to
+ * be reduced IS the antenna's fp32 plane, so detect can write it straight into the caller's buffer and the local
+ * sum needs no kernel at all (a 21-MB copy per second of data that cost 0.085 ms of a 0.68-ms step beside the
+ * channeliser).  pb_set_coadd_target gives the SELECTED buffer set its own d_sum (NULL: back to the internal
+ * plane); pb_coadd_local(h, nseg, that pointer, 0) then only orders the coadd stream behind detect, and
+ * pb_coadd_release -- called after the host has queued the collective (and pb_coadd_finish on the root) on the
+ * coadd stream -- tells the library that the buffer may be overwritten by the set's next batch. */
+int pb_set_coadd_target(pb_handle *h, float *d_sum);
+int pb_coadd_release(pb_handle *h);
 /* Run pb_coadd_local / pb_coadd_finish (and so the collective the host queues between them) on
  * `stream` (a hipStream_t; NULL = the handle's main stream, the default).  On a stream of its own the
  * sum of batch k, its RCCL reduce and the root's requantisation overlap the kernels of batch k+1;

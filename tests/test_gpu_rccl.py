@@ -14,7 +14,10 @@ from helpers import libpb, make_input
 pytestmark = pytest.mark.gpu
 
 
-def test_rccl_world1_pipelined_coadd_equals_single_antenna_codes():
+@pytest.mark.parametrize("target", [False, True])
+def test_rccl_world1_pipelined_coadd_equals_single_antenna_codes(target):
+    """target: detect writes the plane to be reduced straight into the caller's buffer (pb_set_coadd_target, one
+    buffer per set), the local sum launches nothing, pb_coadd_release follows the collective."""
     import torch
     import torch.distributed as dist
     lp = libpb()
@@ -28,7 +31,11 @@ def test_rccl_world1_pipelined_coadd_equals_single_antenna_codes():
         R, S, NSETS, NSTEP = 16, 4, 2, 3
         data = [make_input(50 + k, R, S) for k in range(NSTEP)]
         h = lp.PbHandle(device=0, nant=1, nbit=8, npol=1, rfi_mode=2, rows_per_seg=R, max_seg=S, keep_ave=True, nsets=NSETS)
-        d_sum = torch.zeros(S * h.ave_per_seg, dtype=torch.float32, device=dev)
+        d_sums = [torch.zeros(S * h.ave_per_seg, dtype=torch.float32, device=dev) for _ in range(NSETS if target else 1)]
+        if target:
+            for st in range(NSETS):
+                h.select_set(st)
+                h.set_coadd_target(d_sums[st].data_ptr())
         ts = torch.cuda.Stream(device=dev)
         h.sync()
         h.set_coadd_stream(ts.cuda_stream)
@@ -39,10 +46,13 @@ def test_rccl_world1_pipelined_coadd_equals_single_antenna_codes():
                 for s in range(S):
                     h.submit_planar(0, s, data[k][s, 0], data[k][s, 1])
                 h.process(S)
+                d_sum = d_sums[k % NSETS] if target else d_sums[0]
                 with torch.cuda.stream(ts):
                     h.coadd_local(S, d_sum.data_ptr())
                     dist.reduce(d_sum, dst=0, op=dist.ReduceOp.SUM)          # RCCL, on the coadd stream
                     h.coadd_finish(S, d_sum.data_ptr(), 1, blocking=False)
+                    if target:
+                        h.coadd_release()
             if k >= 1:
                 h.select_set((k - 1) % NSETS)
                 single.append(h.fetch(0, 0, S)["kur"].copy())

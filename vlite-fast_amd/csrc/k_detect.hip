@@ -188,9 +188,34 @@ __global__ void k_coadd_digitise(const float *__restrict__ sum, float scale, uin
     }
 }
 
+// the common case (8 bits, one pol: codes[i] = q(sum[i] * scale)), four samples per thread and step: one 16-byte
+// load, one 4-byte store.  (Not straight into the page-locked host mirror: 256 workgroups waiting on PCIe writes
+// would each hold a CU slot that a channeliser workgroup wants; the 8-workgroup copy kernel does that.)
+__global__ __launch_bounds__(256) void k_coadd_digitise8(const float4 *__restrict__ sum, float scale,
+                                                         uint32_t *__restrict__ codes, size_t n4)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = sum[i];
+        const float x[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};
+        unsigned word = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float tmp = (float)((double)x[j] / 0.02957 + 127.5);
+            const unsigned q = tmp <= 0 ? 0u : (tmp >= 255 ? 255u : (unsigned)(uint8_t)tmp);
+            word |= q << (8 * j);
+        }
+        codes[i] = word;
+    }
+}
+
 hipError_t launch_coadd_digitise(pb_handle *h, int nseg, const float *d_sum, float scale, uint8_t *d_codes,
                                  hipStream_t st)
 {
+    if (h->cfg.nbit == 8 && h->cfg.npol == 1 && h->ave_per_seg == h->trim && (h->trim & 3) == 0) {
+        const size_t n4 = (size_t)nseg * h->trim / 4;
+        k_coadd_digitise8<<<256, 256, 0, st>>>((const float4 *)d_sum, scale, (uint32_t *)d_codes, n4);
+        return hipGetLastError();
+    }
     k_coadd_digitise<<<512, 256, 0, st>>>(d_sum, scale, d_codes, h->ave_per_seg, h->trim, nseg,
                                                  h->cfg.npol, h->cfg.nbit, h->R / PB_NSCRUNCH);
     return hipGetLastError();

@@ -44,6 +44,8 @@ struct Detect2Args {
     float *bp;               // [A][2][2][4096]
     uint8_t *codes;          // [A][2][S][trim]
     float *ave;              // [A][2][S][ave_per_seg] or nullptr
+    float *ave_target;       // antenna 0's plane of stream `target_stream` goes here instead (pb_set_coadd_target)
+    int target_stream;
     size_t trim, ave_per_seg;
     int S, R, nseg;
     float scale, oms, tscale;
@@ -408,6 +410,7 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
         const int cB = cg * 32 + ch;
         uint8_t *codes = a.codes + ((size_t)ant * 2 + stream) * a.S * a.trim;
         float *ave = a.ave ? a.ave + ((size_t)ant * 2 + stream) * a.S * a.ave_per_seg : nullptr;
+        if (a.ave_target && ant == 0 && stream == a.target_stream) ave = a.ave_target;
         BState<NPOL> bs;
         Cursor cu;                       // this wave's next chunk: those of its parity
         cu.init(0, cps);
@@ -504,6 +507,8 @@ hipError_t launch_detect_pow(pb_handle *h, int nseg)
     a.bp = h->d_bp;
     a.codes = h->d_codes;
     a.ave = h->cfg.keep_ave ? h->d_ave : nullptr;
+    a.ave_target = h->cfg.keep_ave ? h->d_coadd_target : nullptr;
+    a.target_stream = h->cfg.rfi_mode == 0 ? 0 : 1;
     a.trim = h->trim;
     a.ave_per_seg = h->ave_per_seg;
     a.S = h->S;

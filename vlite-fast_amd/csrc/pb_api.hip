@@ -163,6 +163,7 @@ static void store_set(pb_handle *h, int i)
     b.d_in = h->d_in; b.d_flags = h->d_flags; b.d_codes = h->d_codes; b.h_codes = h->h_codes;
     b.d_wrow = h->d_wrow; b.d_stats = h->d_stats; b.d_fraw = h->d_fraw; b.d_fkur = h->d_fkur;
     b.d_Praw = h->d_Praw; b.d_Pkur = h->d_Pkur; b.d_ave = h->d_ave; b.d_Xraw = h->d_Xraw; b.d_Xkur = h->d_Xkur;
+    b.d_coadd_target = h->d_coadd_target;
     b.ev_chan = h->ev_chan; b.ev_det = h->ev_det; b.ev_cl = h->ev_cl; b.processed = h->processed;
 }
 
@@ -172,6 +173,7 @@ static void load_set(pb_handle *h, int i)
     h->d_in = b.d_in; h->d_flags = b.d_flags; h->d_codes = b.d_codes; h->h_codes = b.h_codes;
     h->d_wrow = b.d_wrow; h->d_stats = b.d_stats; h->d_fraw = b.d_fraw; h->d_fkur = b.d_fkur;
     h->d_Praw = b.d_Praw; h->d_Pkur = b.d_Pkur; h->d_ave = b.d_ave; h->d_Xraw = b.d_Xraw; h->d_Xkur = b.d_Xkur;
+    h->d_coadd_target = b.d_coadd_target;
     h->ev_chan = b.ev_chan; h->ev_det = b.ev_det; h->ev_cl = b.ev_cl; h->processed = b.processed;
     h->cur_set = i;
 }
@@ -223,6 +225,7 @@ static int create_impl(pb_handle *h)
     h->d_in = h->d_flags = h->d_codes = h->h_codes = nullptr;
     h->d_wrow = h->d_stats = h->d_fraw = h->d_fkur = h->d_Praw = h->d_Pkur = h->d_ave = nullptr;
     h->d_Xraw = h->d_Xkur = nullptr;
+    h->d_coadd_target = nullptr;
     HIPCHK(h, dmalloc(h, &h->d_in, in_elems + 64));   // + overhang of the channeliser's 16-byte row loads
     HIPCHK(h, dmalloc(h, &h->d_flags, A * S * h->nblk_seg));
     HIPCHK(h, hipMemset(h->d_flags, 0, A * S * h->nblk_seg));
@@ -357,6 +360,7 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
     h->s_kur = nullptr;
     h->ev_fftdone = h->ev_kur = h->ev_alldone = nullptr;
     h->last_set = -1;
+    h->d_coadd_target = nullptr;
     h->d_coadd_codes = h->h_coadd_codes = nullptr;
     h->ev_coadd[0] = h->ev_coadd[1] = nullptr;
     h->coadd_slot = h->coadd_last = 0;
@@ -916,6 +920,12 @@ extern "C" int pb_fetch(pb_handle *h, int ant, int seg0, int nseg, uint8_t *raw_
     if (kur_codes) memcpy(kur_codes, c1, (size_t)nseg * h->trim);
     if (ave_raw) HIPCHK(h, hipMemcpy(ave_raw, h->d_ave + (((size_t)ant * 2 + 0) * S + seg0) * h->ave_per_seg,
                                     (size_t)nseg * h->ave_per_seg * sizeof(float), hipMemcpyDeviceToHost));
+    const int cstream = h->cfg.rfi_mode == 0 ? 0 : 1;     // the stream whose plane a coadd target replaces
+    if (h->d_coadd_target && ant == 0 && ((cstream == 0 && ave_raw) || (cstream == 1 && ave_kur))) {
+        HIPCHK(h, hipMemcpy(cstream ? ave_kur : ave_raw, h->d_coadd_target + (size_t)seg0 * h->ave_per_seg,
+                            (size_t)nseg * h->ave_per_seg * sizeof(float), hipMemcpyDeviceToHost));
+        if (cstream) ave_kur = nullptr; else ave_raw = nullptr;
+    }
     if (ave_kur) HIPCHK(h, hipMemcpy(ave_kur, h->d_ave + (((size_t)ant * 2 + 1) * S + seg0) * h->ave_per_seg,
                                     (size_t)nseg * h->ave_per_seg * sizeof(float), hipMemcpyDeviceToHost));
     if (weights) {
@@ -938,7 +948,10 @@ extern "C" int pb_output_dev(pb_handle *h, int ant, int stream, void **codes, vo
     if (check_ant(h, ant)) return PB_EINVAL;
     if (stream < 0 || stream > 1) return fail(h, PB_EINVAL, "stream must be 0 or 1");
     if (codes) *codes = h->d_codes + ((size_t)ant * 2 + stream) * h->S * h->trim;
-    if (ave) *ave = h->d_ave ? h->d_ave + ((size_t)ant * 2 + stream) * h->S * h->ave_per_seg : nullptr;
+    if (ave) {
+        *ave = h->d_ave ? h->d_ave + ((size_t)ant * 2 + stream) * h->S * h->ave_per_seg : nullptr;
+        if (h->d_coadd_target && ant == 0 && stream == (h->cfg.rfi_mode == 0 ? 0 : 1)) *ave = h->d_coadd_target;
+    }
     return PB_OK;
 }
 
@@ -961,7 +974,16 @@ extern "C" int pb_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumula
     // coadd stream of its own (pb_set_coadd_stream) this wait holds up neither the next batch's
     // channeliser nor its detect.
     hipStream_t cs = h->s_coadd ? h->s_coadd : h->stream;
-    HIPCHK(h, hipStreamWaitEvent(cs, h->ev_chan, 0));
+    // The planes come from this set's detect, which runs on another stream.  When the host already knows that it
+    // has finished (e.g. the batch's bytes have been fetched), no device-side wait is queued: a pending
+    // cross-stream wait on that event was measured to cost the whole pipeline 0.12 ms per second of data.
+    if (hipEventQuery(h->ev_chan) != hipSuccess) HIPCHK(h, hipStreamWaitEvent(cs, h->ev_chan, 0));
+    if (h->d_coadd_target && d_sum == h->d_coadd_target && !accumulate) {
+        // nant = 1 with a coadd target: detect wrote the plane into d_sum itself.  Nothing to launch; the
+        // "planes consumed" event is recorded by pb_coadd_release, after the caller's collective.
+        if (nseg > h->processed) return fail(h, PB_EINVAL, "pb_coadd_local: more segments than the batch holds");
+        return PB_OK;
+    }
     hipStream_t s_main = h->stream;
     h->stream = cs;                       // (StageTimer records on h->stream)
     hipError_t e;
@@ -973,6 +995,26 @@ extern "C" int pb_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumula
     if (e == hipSuccess) e = hipEventRecord(h->ev_cl, cs);
     h->stream = s_main;
     HIPCHK(h, e);
+    return PB_OK;
+}
+
+extern "C" int pb_set_coadd_target(pb_handle *h, float *d_sum)
+{
+    if (!h) return PB_EINVAL;
+    if (d_sum && (h->A != 1 || !h->cfg.keep_ave || h->cfg.fft_backend != PB_FFT_LDS))
+        return fail(h, PB_ESTATE, "pb_set_coadd_target needs nant=1, keep_ave=1 and the LDS back end");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, sync_all(h));              // no detect of this handle is writing a plane
+    h->d_coadd_target = d_sum;
+    return PB_OK;
+}
+
+extern "C" int pb_coadd_release(pb_handle *h)
+{
+    if (!h) return PB_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t cs = h->s_coadd ? h->s_coadd : h->stream;
+    HIPCHK(h, hipEventRecord(h->ev_cl, cs));      // what the set's next detect waits for before it writes the planes
     return PB_OK;
 }
 

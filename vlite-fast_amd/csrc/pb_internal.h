@@ -65,6 +65,7 @@ struct pb_handle {
     float *d_bp;           // [A][2 streams][2 pols][4096]
     uint8_t *d_codes;      // [A][2 streams][S][trim]
     float *d_ave;          // [A][2 streams][S][ave_per_seg]
+    float *d_coadd_target; // nant = 1: the coadd stream's plane of antenna 0 goes here instead (pb_set_coadd_target)
     float *d_frb_delays;   // [6251]
     uint8_t *d_hist_in;    // taps=4: [A][2][3][12512] last three rows of the previous batch
     uint8_t *d_hist_flags; // taps=4: [A][3][25] their kurtosis flags (1 = flagged / no data)
@@ -80,7 +81,7 @@ struct pb_handle {
     int processed;         // segments of the last pb_process on this set
     struct BufSet {
         uint8_t *d_in, *d_flags, *d_codes, *h_codes;
-        float *d_wrow, *d_stats, *d_fraw, *d_fkur, *d_Praw, *d_Pkur, *d_ave;
+        float *d_wrow, *d_stats, *d_fraw, *d_fkur, *d_Praw, *d_Pkur, *d_ave, *d_coadd_target;
         float2 *d_Xraw, *d_Xkur;
         hipEvent_t ev_chan, ev_det, ev_cl;
         int processed;

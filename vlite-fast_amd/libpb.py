@@ -52,7 +52,7 @@ class PbTimers(C.Structure):
 EXPORTS = ["pb_config_default", "pb_create", "pb_destroy", "pb_last_error", "pb_query",
            "pb_set_stream", "pb_sync", "pb_reset_bandpass", "pb_reset_history", "pb_get_bandpass", "pb_set_bandpass",
            "pb_submit_planar", "pb_submit_planar_dev", "pb_submit_vdif", "pb_submit_vdif_at", "pb_input_dev", "pb_process", "pb_set_frb_params", "pb_select_set", "pb_fetch", "pb_fetch_ptr",
-           "pb_output_dev", "pb_coadd_local", "pb_set_coadd_stream", "pb_coadd_finish", "pb_coadd_fetch_ptr", "pb_profile", "pb_get_timers", "pb_host_alloc", "pb_host_free",
+           "pb_output_dev", "pb_coadd_local", "pb_set_coadd_target", "pb_coadd_release", "pb_set_coadd_stream", "pb_coadd_finish", "pb_coadd_fetch_ptr", "pb_profile", "pb_get_timers", "pb_host_alloc", "pb_host_free",
            "pb_debug_fetch", "pb_channelize_f32", "pb_version", "pb_search_create", "pb_search_create_list", "pb_search_destroy",
            "pb_search_last_error", "pb_search_info", "pb_search_run", "pb_search_set_baseline", "pb_search_peaks",
            "pb_search_timers"]
@@ -105,6 +105,8 @@ def load():
     L.pb_fetch_ptr.argtypes = [vp, C.c_int, C.c_int, C.POINTER(u8p)]
     L.pb_output_dev.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp)]
     L.pb_coadd_local.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.pb_set_coadd_target.argtypes = [vp, vp]
+    L.pb_coadd_release.argtypes = [vp]
     L.pb_set_coadd_stream.argtypes = [vp, vp]
     L.pb_coadd_finish.argtypes = [vp, C.c_int, vp, C.c_int, u8p]
     L.pb_coadd_fetch_ptr.argtypes = [vp, C.c_int, C.POINTER(u8p)]
@@ -291,6 +293,14 @@ class PbHandle(object):
 
     def coadd_local(self, nseg, d_sum_ptr, accumulate=False):
         self._chk(self._L.pb_coadd_local(self._h, nseg, C.c_void_p(d_sum_ptr), int(accumulate)))
+
+    def set_coadd_target(self, d_sum_ptr):
+        """nant = 1: the selected set's detect writes the plane to be reduced straight into d_sum (0 / None: off);
+        coadd_local(nseg, d_sum_ptr) then launches nothing, and coadd_release() follows the collective."""
+        self._chk(self._L.pb_set_coadd_target(self._h, C.c_void_p(d_sum_ptr or None)))
+
+    def coadd_release(self):
+        self._chk(self._L.pb_coadd_release(self._h))
 
     def coadd_finish(self, nseg, d_sum_ptr, nant_total, blocking=True):
         if not blocking:
