@@ -243,13 +243,14 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
         h.sync()
         h.set_coadd_stream(ts.cuda_stream)
 
+    parts = int(os.environ.get("PB_COADD_PARTS", "7"))     # timing experiments: 1 local sum, 2 reduce, 4 finish
+
     def finish_batch(j):
         """Batch j is done on the device once its filterbank bytes are here (collect waits for them), so its
         incoherent-sum leg -- local sum (nothing to launch with a coadd target), RCCL reduce, requantisation on
         the root -- is queued on the coadd stream without a device-side wait for detect, one step behind the
         batch itself, and runs beside the kernels of the batches after it."""
         collect(j)                                    # (selects buffer set j mod NSETS)
-        parts = int(os.environ.get("PB_COADD_PARTS", "7"))     # timing experiments: 1 local sum, 2 reduce, 4 finish
         if coadd and parts:
             ds = d_sums[j % NSETS] if d_sums is not None else d_sum
             with torch.cuda.stream(ts):
