@@ -237,20 +237,38 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
 
 
 // row weights of the PFB mode (see the header comment); overwrites wrow[g]
-__global__ void k_pfb_weights(const uint8_t *__restrict__ flags, size_t flags_ant_stride,
+__global__ void k_pfb_weights(const uint32_t *__restrict__ rowmask, size_t wrow_ant_stride,
                               const uint8_t *__restrict__ hflags, const float *__restrict__ tapE,
-                              float *__restrict__ wrow, size_t wrow_ant_stride, int nrows)
+                              float *__restrict__ wrow, int nrows)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int ant = blockIdx.y;
     if (g >= nrows) return;
-    float s = 0.f;
+    // flag masks of the four contributing rows: the kurtosis kernel's mask words (one load each; reading the 100
+    // flag bytes one after the other made this 40-workgroup kernel take 57 us on the critical path), the
+    // history slots' bytes for the first three rows of a batch
+    unsigned m[4];
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int rr = g - 3 + j;
-        const uint8_t *f = rr >= 0 ? flags + (size_t)ant * flags_ant_stride + (size_t)rr * PB_BLK_PER_FFT
-                                   : hflags + ((size_t)ant * 3 + (3 + rr)) * PB_BLK_PER_FFT;
-        for (int b = 0; b < PB_BLK_PER_FFT; ++b)
-            if (!f[b]) s = s + tapE[j * PB_BLK_PER_FFT + b];
+        if (rr >= 0) {
+            m[j] = rowmask[(size_t)ant * wrow_ant_stride + rr];
+        } else {
+            const uint8_t *f = hflags + ((size_t)ant * 3 + (3 + rr)) * PB_BLK_PER_FFT;
+            unsigned mm = 0;
+            for (int b = 0; b < PB_BLK_PER_FFT; ++b) mm |= (f[b] ? 1u : 0u) << b;
+            m[j] = mm;
+        }
+    }
+    // sum of the unflagged (tap, block) energies, taps then blocks ascending (tapE[100] is that sum with no flag
+    // at all, accumulated in the same order: an unflagged row gets exactly 1)
+    float s = tapE[100];
+    if (m[0] | m[1] | m[2] | m[3]) {
+        s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            for (int b = 0; b < PB_BLK_PER_FFT; ++b)
+                if (!((m[j] >> b) & 1u)) s = s + tapE[j * PB_BLK_PER_FFT + b];
     }
     wrow[(size_t)ant * wrow_ant_stride + g] = s / tapE[100];
 }
@@ -274,14 +292,19 @@ __global__ void k_pfb_history(const uint8_t *__restrict__ in, size_t in_ant_stri
     if (pol == 0 && threadIdx.x == 0) hvalid[ant * 3 + j] = 1;
 }
 
+// row weights of the batch, from the kurtosis flags: queued right behind the kurtosis pass, on its stream
+hipError_t launch_pfb_weights(pb_handle *h, int nseg)
+{
+    if (h->cfg.taps != 4 || !h->cfg.rfi_mode) return hipSuccess;
+    const int nrows = nseg * h->R;
+    dim3 g((nrows + 255) / 256, h->A);
+    k_pfb_weights<<<g, 256, 0, h->stream>>>(pb_rowmask(h), (size_t)h->S * h->R, h->d_hist_flags, h->d_tapE, h->d_wrow, nrows);
+    return hipGetLastError();
+}
+
 hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now)
 {
     const int nrows = nseg * h->R;
-    if (h->cfg.rfi_mode) {
-        dim3 g((nrows + 255) / 256, h->A);
-        k_pfb_weights<<<g, 256, 0, h->stream>>>(h->d_flags, (size_t)h->S * h->nblk_seg, h->d_hist_flags, h->d_tapE,
-                                                h->d_wrow, (size_t)h->S * h->R, nrows);
-    }
     PfbArgs a;
     a.in = h->d_in;
     a.in_ant_stride = (size_t)h->S * 2 * h->seg_samples;

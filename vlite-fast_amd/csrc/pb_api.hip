@@ -790,6 +790,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         if (e == hipSuccess) {
             StageTimer t(h, PB_ST_KURTOSIS);
             e = launch_kurtosis_flag(h, nseg, hipfft);
+            if (e == hipSuccess) e = launch_pfb_weights(h, nseg);   // taps = 4 (the history it reads was written before ev_fftdone)
             t.stop();
         }
         if (overlap) {

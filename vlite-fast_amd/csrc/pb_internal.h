@@ -122,6 +122,7 @@ hipError_t launch_detect_pow(pb_handle *h, int nseg);
 hipError_t launch_copy_out(uint8_t *host_pinned, const uint8_t *dev, size_t nbytes, hipStream_t st);
 hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now);
+hipError_t launch_pfb_weights(pb_handle *h, int nseg);   // taps = 4: after the kurtosis pass, before the channeliser
 hipError_t launch_channelize_f32(pb_handle *h, const float *d_x, int nrows, int taps, float2 *d_out);
 hipError_t launch_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate, hipStream_t st);
 hipError_t launch_coadd_digitise(pb_handle *h, int nseg, const float *d_sum, float scale,
