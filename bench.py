@@ -274,14 +274,20 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
                 state["sink"] += int(v[0])
             state["coadds"] += 1
 
+    trace = [] if os.environ.get("PB_BENCH_TRACE") else None      # timing experiments: host time per step
+
     def step():
         k = state["k"]
+        ta = time.perf_counter()
         h.select_set(k % NSETS)
         if ingest:
             h.submit_vdif(0, 0, blocks[k % len(blocks)].numpy(), second=3600, frame0=0)
         h.process(S)
+        tb = time.perf_counter()
         if k >= NSETS - 1:
             finish_batch(k - (NSETS - 1))
+        if trace is not None:
+            trace.append((tb - ta, time.perf_counter() - tb))
         state["k"] = k + 1
 
     def drain():
@@ -298,6 +304,11 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
         dist.barrier()
     h.timers(reset=True)
     h.profile(True)
+    # no cyclic-GC pass of the interpreter inside the timed region: a full collection over the objects torch's
+    # import leaves behind takes 30-40 ms -- sixty steps' worth -- and fell into a sub-record's 66 steps
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -307,6 +318,12 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
+    if trace is not None:
+        tr = np.array(trace[-steps:]) * 1e3
+        print("host ms per step (taps %d%s): process mean %.3f max %.3f; collect mean %.3f max %.3f; slowest steps %s"
+              % (taps, ", ingest" if ingest else "", tr[:, 0].mean(), tr[:, 0].max(), tr[:, 1].mean(), tr[:, 1].max(),
+                 np.argsort(-tr.sum(axis=1))[:6].tolist()), file=sys.stderr)
     h.profile(False)
     tm = h.timers(reset=True)
     if world > 1:
