@@ -304,7 +304,6 @@ hipError_t launch_pfb_weights(pb_handle *h, int nseg)
 
 hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now)
 {
-    const int nrows = nseg * h->R;
     PfbArgs a;
     a.in = h->d_in;
     a.in_ant_stride = (size_t)h->S * 2 * h->seg_samples;
@@ -333,8 +332,17 @@ hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now)
     a.inject_now = inject_now;
     dim3 grid((unsigned)h->R, (unsigned)(nseg * 2), (unsigned)h->A);
     k_channelize_pfb<<<grid, 256, 0, h->stream>>>(a);
+    return hipGetLastError();
+}
+
+// keep the batch's last three rows and their flags for the next call (queued behind the channeliser, after the
+// event that releases detect: it is not on the path to the output)
+hipError_t launch_pfb_history(pb_handle *h, int nseg)
+{
+    const int nrows = nseg * h->R;
     dim3 gh(3, 2, h->A);
-    k_pfb_history<<<gh, 256, 0, h->stream>>>(h->d_in, a.in_ant_stride, h->seg_samples, h->d_flags, a.flags_ant_stride,
-                                             h->d_hist_in, h->d_hist_flags, h->d_hist_valid, h->R, nrows);
+    k_pfb_history<<<gh, 256, 0, h->stream>>>(h->d_in, (size_t)h->S * 2 * h->seg_samples, h->seg_samples, h->d_flags,
+                                             (size_t)h->S * h->nblk_seg, h->d_hist_in, h->d_hist_flags, h->d_hist_valid,
+                                             h->R, nrows);
     return hipGetLastError();
 }

@@ -213,6 +213,7 @@ static int create_impl(pb_handle *h)
     HIPCHK(h, hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_fftdone, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_kur, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_hist, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_alldone, hipEventDisableTiming));
     const size_t A = h->A, S = h->S, R = h->R;
     const size_t in_elems = A * S * 2 * h->seg_samples;
@@ -358,7 +359,7 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
     h->s_det = nullptr;
     h->s_copy = nullptr;
     h->s_kur = nullptr;
-    h->ev_fftdone = h->ev_kur = h->ev_alldone = nullptr;
+    h->ev_fftdone = h->ev_kur = h->ev_alldone = h->ev_hist = nullptr;
     h->last_set = -1;
     h->d_coadd_target = nullptr;
     h->d_coadd_codes = h->h_coadd_codes = nullptr;
@@ -421,6 +422,7 @@ extern "C" void pb_destroy(pb_handle *h)
     if (h->s_copy) (void)hipStreamDestroy(h->s_copy);
     if (h->s_kur) { (void)hipStreamSynchronize(h->s_kur); (void)hipStreamDestroy(h->s_kur); }
     if (h->ev_fftdone) (void)hipEventDestroy(h->ev_fftdone);
+    if (h->ev_hist) (void)hipEventDestroy(h->ev_hist);
     if (h->ev_kur) (void)hipEventDestroy(h->ev_kur);
     if (h->ev_alldone) (void)hipEventDestroy(h->ev_alldone);
     drain_timers(h);
@@ -790,7 +792,10 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         if (e == hipSuccess) {
             StageTimer t(h, PB_ST_KURTOSIS);
             e = launch_kurtosis_flag(h, nseg, hipfft);
-            if (e == hipSuccess) e = launch_pfb_weights(h, nseg);   // taps = 4 (the history it reads was written before ev_fftdone)
+            // taps = 4: the weights read the history the previous batch left (and the input staged after this
+            // point overwrites rows that the history kernel reads)
+            if (e == hipSuccess && h->cfg.taps == 4) e = hipStreamWaitEvent(h->stream, h->ev_hist, 0);
+            if (e == hipSuccess) e = launch_pfb_weights(h, nseg);
             t.stop();
         }
         if (overlap) {
@@ -816,6 +821,10 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         t.stop();
     }
     HIPCHK(h, hipEventRecord(h->ev_fftdone, h->stream));
+    if (h->cfg.taps == 4 && !hipfft) {
+        HIPCHK(h, launch_pfb_history(h, nseg));
+        HIPCHK(h, hipEventRecord(h->ev_hist, h->stream));
+    }
     h->last_set = h->cur_set;
     // With two or more buffer sets, detect + D2H of this batch run on the second stream so that they
     // overlap the NEXT batch's kurtosis and channeliser.  Detect is latency-bound on its serial

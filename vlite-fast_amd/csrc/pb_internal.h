@@ -92,6 +92,7 @@ struct pb_handle {
     hipStream_t s_copy;    // copy-out of the filterbank bytes in pipelined mode, so that it does not hold up the next detect
     hipStream_t s_kur;     // kurtosis of the next batch, beside detect of the previous one
     hipEvent_t ev_fftdone, ev_kur, ev_alldone;
+    hipEvent_t ev_hist;    // taps = 4: the batch's last rows and flags have been kept for the next one
     int last_set;          // buffer set of the previous pb_process (-1: none)
     uint8_t *d_coadd_codes, *h_coadd_codes;   // [2][S*trim] coadded bytes (device / pinned), lazily
     hipEvent_t ev_coadd[2];
@@ -122,7 +123,8 @@ hipError_t launch_detect_pow(pb_handle *h, int nseg);
 hipError_t launch_copy_out(uint8_t *host_pinned, const uint8_t *dev, size_t nbytes, hipStream_t st);
 hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now);
-hipError_t launch_pfb_weights(pb_handle *h, int nseg);   // taps = 4: after the kurtosis pass, before the channeliser
+hipError_t launch_pfb_weights(pb_handle *h, int nseg);
+hipError_t launch_pfb_history(pb_handle *h, int nseg);   // taps = 4: after the channeliser (off the path to detect)   // taps = 4: after the kurtosis pass, before the channeliser
 hipError_t launch_channelize_f32(pb_handle *h, const float *d_x, int nrows, int taps, float2 *d_out);
 hipError_t launch_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate, hipStream_t st);
 hipError_t launch_coadd_digitise(pb_handle *h, int nseg, const float *d_sum, float scale,
