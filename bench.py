@@ -12,10 +12,16 @@ Contract:  python bench.py --gpus N --steps K --warmup W
             ingest  the same step with every second arriving from page-locked host memory as VDIF
                     frames through pb_submit_vdif (PCIe-inclusive; never `value`);
             search  one heimdall-sized gulp of the downstream dedispersion + boxcar search.
-  N > 1   launched one rank per GPU by torch.distributed.run; antennas shard one per GPU
-          (weak scaling; BASELINE configs[3] is this sharding with 2 antennas per GPU:
-          --ant-per-gpu 2) and the per-step incoherent sum of the excised fp32 planes is an
-          RCCL reduce to rank 0 over xGMI, which requantises the coadded second.
+  N > 1   one rank per GPU: either a launcher has started them already (torch.distributed.run sets
+          WORLD_SIZE, which must equal N) or `python bench.py --gpus N` starts them itself as child
+          processes under torch.distributed.run before anything touches the GPU and relays rank 0's line and
+          the exit code.  Fewer GPUs than ranks is an error (not a wrap onto one card).  Antennas shard one per
+          GPU (weak scaling) and the per-step incoherent sum of the excised fp32 planes is an RCCL reduce to
+          rank 0 over xGMI, which requantises the coadded second; the line then carries `rccl_ranks`, and at
+          N = 8 a `configs3` sub-record (BASELINE configs[3]: 16 antennas, 2 per GPU).
+Timing: W warm-up steps + K timed steps straight after set-up give `ms_per_step_cold`; then 100 untimed
+steps, W warm-up steps and `--regions` (5) back-to-back regions of exactly K steps each, every one bracketed by
+barrier + synchronise, MAX over ranks: `ms_per_step` / `value` are the MEDIAN region, min and max beside it.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -141,16 +147,17 @@ def cpu_baseline():
                       "rows split over a %d-process pool (this job's share of the host's cores)" % ncores}
 
 
-def measured_traffic(stage, args, taps):
+def measured_traffic(stage, args, taps, A=1):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of THIS build
     (tools/profile_gpu.sh + tools/summarise_profile.py; FETCH_SIZE / WRITE_SIZE collected in separate passes
     and corrected as MI355X_MICROARCH.md prescribes).  None when no summary matches the configuration or
     when the kernels have changed since the profile was taken (source hash recorded in the summary)."""
     import glob
-    if (args.backend != "lds" or args.rfi_mode != 2 or args.seg_per_step != 10 or args.ant_per_gpu != 1
-            or args.rfi_frac or taps != 1):
+    if args.backend != "lds" or args.rfi_mode != 2 or args.seg_per_step != 10 or A != 1 or args.rfi_frac:
         return None
-    names = {"kurtosis": "k_kurtosis_row", "channelize": "k_channelize", "detect": "k_detect2"}
+    names = {"kurtosis": "k_kurtosis_row", "channelize": "k_channelize_pfb" if taps == 4 else "k_channelize",
+             "detect": "k_detect2"}
+    want = names.get(stage)
     best = None
     sha = kernel_source_hash()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
@@ -160,8 +167,10 @@ def measured_traffic(stage, args, taps):
             continue
         if d.get("kernel_source_sha16") != sha:
             continue
+        if ("taps=%d" % taps) not in d.get("bench_config", {}).get("workload", ""):
+            continue
         for k, t in d.get("kernels", {}).items():
-            if k.startswith(names.get(stage, "?")):
+            if k == want or k.startswith(want + "<"):
                 best = int(t["hbm_bytes_per_launch"])
     return best
 
@@ -182,10 +191,17 @@ def algorithmic_bytes(args, h, n, world, taps):
     return alg
 
 
-def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmup, ingest=False, coadd=None):
-    """One timed run of `steps` steps.  ingest: every second arrives as VDIF frames from page-locked host
+def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmup, ingest=False, coadd=None,
+              ant_per_gpu=None, regions=None):
+    """One measurement of the pipeline: a COLD timed region (the caller's W warm-up steps, then K timed steps, on a
+    GPU that has just been set up: what the driver's literal command sees without preconditioning), then
+    PRECONDITION_STEPS untimed steps + W warm-up steps and `regions` back-to-back timed regions of exactly K steps
+    each (every one bracketed by barrier + synchronise on both sides, MAX over ranks).  ms_per_step = the median
+    region; min / max are reported beside it.  ingest: every second arrives as VDIF frames from page-locked host
     memory (pb_submit_vdif), otherwise the samples are resident in HBM."""
-    S, A = args.seg_per_step, args.ant_per_gpu
+    S = args.seg_per_step
+    A = args.ant_per_gpu if ant_per_gpu is None else ant_per_gpu
+    regions = args.regions if regions is None else regions
     if coadd is None:
         coadd = world > 1        # the incoherent sum (local sum -> reduce -> requantise on the root) is part of the step
     backend = lp.FFT_LDS if args.backend == "lds" else lp.FFT_HIPFFT
@@ -299,35 +315,49 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
         state["k"] = 0
 
     # The GPU reaches its sustained clocks only after ~30 ms of work (20-step chunks from a cold start: 0.81, 0.66,
-    # then 0.64 ms per step), which is longer than a short warm-up plus a short timed region last together: run the
-    # pipeline untimed for PRECONDITION_STEPS first (reported in the JSON line), then the W warm-up steps.
-    # no cyclic-GC pass of the interpreter inside the timed region: a full collection over the objects torch's
-    # import leaves behind takes 30-40 ms -- sixty steps' worth -- and fell into a sub-record's 66 steps.  Collected
-    # here, before the warm-up, and switched off until the timed steps are done: 40 ms of host work between the
-    # warm-up and the timed region would let the GPU clock down again.
+    # then 0.64 ms per step), which is longer than a short warm-up plus a short timed region last together.  Both
+    # figures are reported: the COLD region (W warm-up steps, K timed steps, nothing before them) and the sustained
+    # ones (PRECONDITION_STEPS untimed steps, W warm-up steps, then `regions` timed regions of K steps back to back).
+    # No cyclic-GC pass of the interpreter inside a timed region: a full collection over the objects torch's
+    # import leaves behind takes 30-40 ms -- sixty steps' worth.  Collected here and switched off until the timed
+    # steps are done (40 ms of host work between warm-up and timing would also let the GPU clock down again).
     import gc
     gc.collect()
     gc.disable()
     h.profile(True)      # (also while warming up: the stage timers' events are created once and then reused)
+
+    def fence():
+        drain()
+        h.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def timed_region():
+        """EXACTLY `steps` steps between two fences; seconds, MAX over ranks"""
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    for _ in range(warmup):
+        step()
+    fence()
+    dt_cold = timed_region()
     for _ in range(PRECONDITION_STEPS + warmup):
         step()
-    drain()
-    h.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    fence()
     h.timers(reset=True)
     h.profile(True)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    drain()
-    h.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dts = [timed_region() for _ in range(max(1, regions))]
     gc.enable()
+    dt = float(np.median(dts))
     if trace is not None:
         tr = np.array(trace[-steps:]) * 1e3
         print("host ms per step (taps %d%s): process mean %.3f max %.3f; collect mean %.3f max %.3f; slowest steps %s"
@@ -335,10 +365,7 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
                  np.argsort(-tr.sum(axis=1))[:6].tolist()), file=sys.stderr)
     h.profile(False)
     tm = h.timers(reset=True)
-    if world > 1:
-        t = torch.tensor([dt], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    nsteps_timed = steps * len(dts)
     res = None
     if rank == 0:
         samples = float(nant_total) * S * n * steps          # dual-pol samples
@@ -349,12 +376,16 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
         avg_ms = stages[dom][0] / stages[dom][1]
         per_launch = alg[dom] * S * A
         achieved = per_launch / (avg_ms * 1e-3) / 1e9
-        res = {"msamp": msamp, "ms_per_step": dt / steps * 1e3, "nant_total": nant_total,
+        res = {"msamp": msamp, "ms_per_step": dt / steps * 1e3, "nant_total": nant_total, "ant_per_gpu": A,
+               "ms_per_step_cold": dt_cold / steps * 1e3,
+               "regions": {"n": len(dts), "steps_each": steps, "ms_per_step_median": round(dt / steps * 1e3, 4),
+                           "ms_per_step_min": round(min(dts) / steps * 1e3, 4),
+                           "ms_per_step_max": round(max(dts) / steps * 1e3, 4)},
                "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                            "traffic": measured_traffic(dom, args, taps), "avg_launch_ms": round(avg_ms, 4),
+                            "traffic": measured_traffic(dom, args, taps, A), "avg_launch_ms": round(avg_ms, 4),
                             "algorithmic_bytes_per_launch": per_launch},
-               "stage_ms_per_step": {k: round(v[0] / steps, 4) for k, v in tm.items() if v[1] > 0}}
+               "stage_ms_per_step": {k: round(v[0] / nsteps_timed, 4) for k, v in tm.items() if v[1] > 0}}
     h.close()
     return res
 
@@ -420,11 +451,13 @@ def search_record(lp, torch):
                 "nsamps_gulp": T, "stage_ms": {k: round(v, 3) for k, v in s.timers().items()}}
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--regions", type=int, default=5,
+                    help="back-to-back timed regions of --steps steps each (median reported, min / max beside it)")
     ap.add_argument("--backend", choices=["lds", "hipfft"], default="lds")
     ap.add_argument("--rfi-mode", type=int, default=2)
     ap.add_argument("--nbit", type=int, default=8)
@@ -435,16 +468,81 @@ def main():
     ap.add_argument("--taps", type=int, default=1, help="1 = rectangular window (reference GPU path), 4 = PFB")
     ap.add_argument("--nsets", type=int, default=2, help="buffer sets (1 = no batch pipelining)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal)")
+    ap.add_argument("--share-gpus", action="store_true",
+                    help="rehearsal only: let more ranks than there are GPUs run (ranks wrap onto the cards); "
+                         "without it a run with fewer GPUs than ranks fails")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the ranks --gpus N starts (0: pick one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the taps4 / ingest / search sub-records")
+    ap.add_argument("--no-extras", action="store_true", help="skip the taps4 / ingest / search / configs3 sub-records")
     ap.add_argument("--coadd-selftest", action="store_true",
                     help="N = 1 only: print the step with the incoherent-sum leg of the N > 1 path switched on "
                          "(fp32 planes kept, local sum, RCCL reduce in a one-rank group, requantisation) instead of the bench line")
-    args = ap.parse_args()
+    return ap
+
+
+def launcher_argv(args, argv, port):
+    """Command line of the N ranks `bench.py --gpus N` starts when no launcher has started them already: one
+    process per GPU under torch.distributed.run on this node, the way scripts/start_coadd:20-58 of the reference
+    starts one coadder rank per antenna host under mpirun.  Rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def pick_json_line(text):
+    """the bench line among whatever else the ranks printed: the last line that parses as a JSON object"""
+    for line in reversed(text.splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                d = json.loads(line)
+            except ValueError:
+                continue
+            if isinstance(d, dict):
+                return line
+    return None
+
+
+def launch_ranks(args, argv, run=None):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks as CHILD
+    processes (this process never touches the GPU and nothing is exec'd), relay rank 0's JSON line and the
+    children's exit code."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = launcher_argv(args, argv, port)
+    p = (run or subprocess.run)(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = pick_json_line(p.stdout or "")
+    if line is not None:
+        print(line)
+    else:
+        sys.stdout.write(p.stdout or "")
+    sys.stdout.flush()
+    if p.returncode == 0 and line is None:
+        print("bench.py: the ranks printed no JSON line", file=sys.stderr)
+        return 1
+    return p.returncode
+
+
+def main():
+    argv = sys.argv[1:]
+    args = build_parser().parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, argv))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     # the CPU baseline forks a process pool: before torch / HIP are initialised in this process
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -452,10 +550,15 @@ def main():
 
     import torch
     import torch.distributed as dist
+    ndev = torch.cuda.device_count()          # (does not initialise the GPU)
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if world > ndev and not args.share_gpus:
+        raise SystemExit("bench.py: --gpus %d but this node shows %d GPU(s); one rank per GPU "
+                         "(--share-gpus wraps ranks onto the cards for a rehearsal)" % (world, ndev))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    ndev = torch.cuda.device_count()
-    local = local % max(ndev, 1)          # (rehearsals may put several ranks on one card)
+    local = local % ndev                      # (only differs under --share-gpus)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -480,6 +583,10 @@ def main():
         dist.destroy_process_group()
         return
     r = run_chain(torch, dist, lp, args, dev, local, rank, world, args.taps, args.steps, args.warmup)
+    # BASELINE configs[3] on the whole node: 16 antennas = 2 per GPU on 8 GPUs (every rank takes part)
+    c3 = None
+    if world == 8 and A == 1 and not args.no_extras and args.taps == 1:
+        c3 = run_chain(torch, dist, lp, args, dev, local, rank, world, 1, args.steps, args.warmup, ant_per_gpu=2)
 
     if rank == 0:
         msamp, nant_total = r["msamp"], r["nant_total"]
@@ -490,6 +597,7 @@ def main():
             "metric": "Msamp/s/antenna (dual-pol) and x real-time @128 MS/s; % HBM roofline",
             "value": round(msamp, 1), "unit": "Msamp/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "precondition_steps": PRECONDITION_STEPS, "ms_per_step": round(r["ms_per_step"], 4),
+            "ms_per_step_cold": round(r["ms_per_step_cold"], 4), "timed_regions": r["regions"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic genbase-style 8-bit Gaussian baseband (mean 128.5, sigma 16.9 codes), "
                     "%g%% of 500-sample blocks with impulsive RFI; resident in HBM" % (100 * args.rfi_frac),
@@ -500,9 +608,22 @@ def main():
                        "parallelism": "antenna-per-GPU" + ("+rccl-reduce-coadd" if world > 1 else "")},
             "msamp_per_antenna": round(msamp / nant_total, 1),
             "x_realtime_per_antenna": round(msamp / nant_total / 128.0, 1),
+            "x_realtime_per_antenna_cold": round(msamp / nant_total / 128.0 * r["ms_per_step"] / r["ms_per_step_cold"], 1),
             "roofline": r["roofline"],
             "stage_ms_per_step": r["stage_ms_per_step"],
         }
+        if world > 1:
+            out["rccl_ranks"] = dist.get_world_size()
+            out["dist_backend"] = "%s (%s)" % (dist.get_backend(), "RCCL" if args.dist_backend == "nccl" else "rehearsal")
+            out["gpus_visible"] = ndev
+        if c3 is not None:
+            out["configs3"] = {"antennas": c3["nant_total"], "antennas_per_gpu": 2, "value": round(c3["msamp"], 1),
+                               "unit": "Msamp/s", "ms_per_step": round(c3["ms_per_step"], 4),
+                               "ms_per_step_cold": round(c3["ms_per_step_cold"], 4), "timed_regions": c3["regions"],
+                               "x_realtime_per_antenna": round(c3["msamp"] / c3["nant_total"] / 128.0, 1),
+                               "stage_ms_per_step": c3["stage_ms_per_step"],
+                               "note": "BASELINE configs[3]: 16 antennas, 2 per GPU, fp32 RCCL reduce of the locally "
+                                       "pre-summed planes to rank 0, which requantises the coadded second"}
         if world == 1:
             try:
                 out["roofline"]["alone"] = alone_record(torch, lp, args, dev, local, args.taps)
@@ -511,12 +632,15 @@ def main():
         if world == 1 and not args.no_extras and args.taps == 1 and A == 1:
             nsub = max(20, 2 * args.steps // 3)      # (short runs time the pipeline's fill and drain)
             t4 = run_chain(torch, dist, lp, args, dev, local, rank, world, 4, nsub, min(args.warmup, 5))
-            out["taps4"] = {"ms_per_step": round(t4["ms_per_step"], 4), "value": round(t4["msamp"], 1), "unit": "Msamp/s",
-                            "x_realtime_per_antenna": round(t4["msamp"] / 128.0, 1), "steps": nsub,
+            out["taps4"] = {"ms_per_step": round(t4["ms_per_step"], 4), "ms_per_step_cold": round(t4["ms_per_step_cold"], 4),
+                            "timed_regions": t4["regions"], "value": round(t4["msamp"], 1), "unit": "Msamp/s",
+                            "x_realtime_per_antenna": round(t4["msamp"] / 128.0, 1),
+                            "x_realtime_per_antenna_cold": round(t4["msamp"] / 128.0 * t4["ms_per_step"] / t4["ms_per_step_cold"], 1),
+                            "steps": nsub,
                             "roofline": dict(t4["roofline"], alone=alone_record(torch, lp, args, dev, local, 4)),
                             "stage_ms_per_step": t4["stage_ms_per_step"],
                             "note": "4-tap Hamming WOLA window (analysis/baseband.py:1207-1237) in the streaming path"}
-            ing = run_chain(torch, dist, lp, args, dev, local, rank, world, 1, nsub, min(args.warmup, 5), ingest=True)
+            ing = run_chain(torch, dist, lp, args, dev, local, rank, world, 1, nsub, min(args.warmup, 5), ingest=True, regions=1)
             gbs = 2 * (S * ing_frames(S) * 5032) / (ing["ms_per_step"] * 1e-3) / 1e9
             out["ingest"] = {"ms_per_step": round(ing["ms_per_step"], 4), "value": round(ing["msamp"], 1), "unit": "Msamp/s",
                              "x_realtime_per_antenna": round(ing["msamp"] / 128.0, 1), "steps": nsub,

@@ -1,0 +1,81 @@
+"""bench.py --gpus N must really start N ranks (round-2 verdict: the flag was parsed and ignored).  No GPU here:
+the argv, the relay of rank 0's JSON line and exit code, and the refusal paths are what is checked; one real launch
+shows that the children are started under torch.distributed.run and that their failure (no GPU in this container)
+comes back as a non-zero exit code instead of a 1-GPU line."""
+import json
+import os
+import subprocess
+import sys
+import types
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    import bench
+    return bench
+
+
+def test_launcher_argv_is_one_rank_per_gpu_on_localhost():
+    b = _bench()
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    args = b.build_parser().parse_args(argv)
+    cmd = b.launcher_argv(args, argv, 29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == argv                      # the ranks get the caller's flags, --gpus included
+
+
+def test_relay_picks_rank0_json_line_and_exit_code(capsys):
+    b = _bench()
+    argv = ["--gpus", "2"]
+    args = b.build_parser().parse_args(argv)
+    line = json.dumps({"metric": "m", "value": 1.0, "n_gpus": 2, "rccl_ranks": 2})
+    seen = {}
+
+    def fake_run(cmd, env, stdout, text):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=0, stdout="W0000 some launcher chatter\n" + line + "\n[rank1] bye\n")
+
+    rc = b.launch_ranks(args, argv, run=fake_run)
+    out = capsys.readouterr().out.strip().splitlines()
+    assert rc == 0 and out == [line]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert "WORLD_SIZE" not in seen["env"] or seen["env"]["WORLD_SIZE"] == os.environ.get("WORLD_SIZE")
+
+    def failing(cmd, env, stdout, text):
+        return types.SimpleNamespace(returncode=3, stdout="")
+
+    assert b.launch_ranks(args, argv, run=failing) == 3
+
+    def silent(cmd, env, stdout, text):
+        return types.SimpleNamespace(returncode=0, stdout="no json here\n")
+
+    assert b.launch_ranks(args, argv, run=silent) == 1     # success without a line is a failure
+
+
+def test_world_size_must_equal_gpus():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "--gpus 4 but the launcher started 2" in p.stderr
+
+
+def test_gpus2_starts_two_ranks_and_relays_their_failure():
+    """No GPU in this container: both ranks refuse ("needs a GPU"), torchrun fails, bench.py --gpus 2 fails --
+    it no longer prints a 1-GPU line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU host: the real run is the driver's")
+    assert p.returncode != 0
+    assert p.stdout.strip() == "" or "n_gpus" not in p.stdout
+    assert "GPU" in p.stderr
