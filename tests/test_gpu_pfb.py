@@ -111,3 +111,174 @@ def test_pfb_weights_and_excision(oracle):
     clean = np.array([g >= 3 and not flags[g - 3:g + 1].any() for g in range(nseg * R)])
     assert clean.any() and np.all(w[clean] == 1.0) and w[0] < w[1] < w[2] < 1.0
     assert (o2["kur"] != o2["raw"]).any()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The taps = 4 configuration AS BENCHMARKED: two buffer sets (batches pipelined over the library's streams, the
+# history of batch k kept behind ev_hist), RFI mode 2 (both streams; excision zeroes the flagged blocks of every
+# contributing row and the row weight is the unflagged fraction of the window's energy), R = 1024 (the XCD-aware
+# row mapping of k_channelize_pfb).  The oracle is the reference's kernels composed around the same fp32 FIR.
+
+def _tap_energy_sequential(t):
+    """E[j][b] exactly as pb_create evaluates it: a sequential double sum of t*t over the block, rounded to float"""
+    E = np.empty((4, 25), np.float32)
+    for j in range(4):
+        for b in range(25):
+            e = 0.0
+            for v in t[j, b * 500:(b + 1) * 500].astype(np.float64):
+                e += v * v
+            E[j, b] = np.float32(e)
+    return E
+
+
+def _oracle_pfb_chain_mode2(oracle, data, Rr):
+    """data: u8 [nseg_total][2][Rr*12500], the whole stream (all batches).  Returns (raw codes, excised codes,
+    weights, flags) of RFI mode 2, npol 1, 8 bits: convertarray -> kurtosis -> compute_dagostino -> flags;
+    raw: FIR -> FFT -> detect_and_normalize2 -> pscrunch -> tscrunch -> sel_and_dig_8b;
+    excised: apply_kurtosis zeroing of every row -> FIR -> FFT -> detect_and_normalize3 (window-energy weights)
+    -> pscrunch_weights -> tscrunch_weights -> sel_and_dig_8b."""
+    L = oracle.lib()
+    fp = C.POINTER(C.c_float)
+    nseg = data.shape[0]
+    rows = nseg * Rr
+    t = _taps32(oracle)
+    volts = [oracle.convertarray(np.concatenate([data[s, p] for s in range(nseg)])) for p in range(2)]
+    kur = np.concatenate([oracle.kurtosis(v)[1] for v in volts])
+    dag = oracle.compute_dagostino(kur)
+    nb = rows * 25
+    flags = (dag[:nb] > 3.0).reshape(rows, 25)
+    # window-energy weights with the library's own E (sequential double sums)
+    E = _tap_energy_sequential(t)
+    tot = np.float32(0)
+    for v in E.ravel():
+        tot = np.float32(tot + v)
+    w = np.empty(rows, np.float32)
+    for g in range(rows):
+        rr = [flags[g - 3 + j] if g - 3 + j >= 0 else np.ones(25, bool) for j in range(4)]
+        if not np.any(rr):
+            w[g] = np.float32(1.0)
+            continue
+        s = np.float32(0)
+        for j in range(4):
+            for b in range(25):
+                if not rr[j][b]:
+                    s = np.float32(s + E[j, b])
+        w[g] = np.float32(s / tot)
+
+    def spectra(v):
+        v = v.reshape(-1, NFFT)
+        pad = np.concatenate([np.zeros((3, NFFT), np.float32), v])
+        acc = t[0] * pad[0:rows]
+        for j in (1, 2, 3):
+            acc = (acc + t[j] * pad[j:j + rows]).astype(np.float32)
+        return oracle.rfft(acc.ravel())
+
+    spec_raw = [spectra(volts[p]) for p in range(2)]
+    spec_kur = []
+    for p in range(2):
+        z = volts[p].reshape(rows, 25, 500).copy()
+        z[flags] = 0.0
+        spec_kur.append(spectra(z.ravel()))
+    scale = np.float32((12500.0 / 128000000 * 8) / 1.0)
+    bp_raw = np.zeros(2 * NCHAN, np.float32)
+    bp_kur = np.zeros(2 * NCHAN, np.float32)
+    codes_raw, codes_kur = [], []
+    u8p = C.POINTER(C.c_uint8)
+    for s in range(nseg):
+        sl = slice(s * Rr, (s + 1) * Rr)
+        fo = np.ascontiguousarray(np.stack([spec_raw[0][sl], spec_raw[1][sl]])).view(np.float32)
+        L.orc_detect_and_normalize2(fo.ctypes.data_as(fp), bp_raw.ctypes.data_as(fp), C.c_float(scale), Rr)
+        L.orc_pscrunch(fo.ctypes.data_as(fp), Rr * NCHAN)
+        ave = np.zeros(Rr // 8 * NCHAN, np.float32)
+        L.orc_tscrunch(fo.ctypes.data_as(fp), ave.ctypes.data_as(fp), ave.size)
+        out = np.zeros(Rr // 8 * 4096, np.uint8)
+        L.orc_sel_and_dig_8b(ave.ctypes.data_as(fp), out.ctypes.data_as(u8p), out.size, 1, Rr // 8)
+        codes_raw.append(out)
+        fk = np.ascontiguousarray(np.stack([spec_kur[0][sl], spec_kur[1][sl]])).view(np.float32)
+        kw = np.ascontiguousarray(np.concatenate([w[sl], w[sl]]))
+        L.orc_detect_and_normalize3(fk.ctypes.data_as(fp), kw.ctypes.data_as(fp), bp_kur.ctypes.data_as(fp),
+                                    C.c_float(scale), Rr)
+        L.orc_pscrunch_weights(fk.ctypes.data_as(fp), kw.ctypes.data_as(fp), Rr * NCHAN)
+        avek = np.zeros(Rr // 8 * NCHAN, np.float32)
+        L.orc_tscrunch_weights(fk.ctypes.data_as(fp), avek.ctypes.data_as(fp), kw.ctypes.data_as(fp), avek.size)
+        outk = np.zeros(Rr // 8 * 4096, np.uint8)
+        L.orc_sel_and_dig_8b(avek.ctypes.data_as(fp), outk.ctypes.data_as(u8p), outk.size, 1, Rr // 8)
+        codes_kur.append(outk)
+    return np.concatenate(codes_raw), np.concatenate(codes_kur), w, flags
+
+
+def _run_pipelined(lp, batches, Rr, rfi_mode, nsets):
+    """bench.py's order of calls: batch k goes to buffer set k mod nsets (re-staged every time), its bytes are
+    collected nsets - 1 batches later"""
+    S = batches[0].shape[0]
+    raw, kur, wts = [], [], []
+
+    def collect(h, j):
+        h.select_set(j % nsets)
+        o = h.fetch(0, 0, S, raw=rfi_mode != 1, kur=rfi_mode != 0, weights=rfi_mode != 0)
+        raw.append(o["raw"])
+        kur.append(o["kur"])
+        wts.append(o["weights"])
+
+    with lp.PbHandle(nbit=8, rfi_mode=rfi_mode, taps=4, rows_per_seg=Rr, max_seg=S, nsets=nsets) as h:
+        for k, d in enumerate(batches):
+            h.select_set(k % nsets)
+            for s in range(S):
+                h.submit_planar(0, s, d[s, 0], d[s, 1])
+            h.process(S)
+            if k >= nsets - 1:
+                collect(h, k - (nsets - 1))
+        for j in range(max(0, len(batches) - (nsets - 1)), len(batches)):
+            collect(h, j)
+    return raw, kur, wts
+
+
+def test_pfb_pipelined_two_sets_mode0_bit_exact(oracle):
+    """(a) nsets = 2, four batches re-staged into the reused sets: the carried rows of batch k (history kernel behind
+    ev_hist) reach batch k + 1 although its input was staged while batch k was still running."""
+    lp = libpb()
+    S, NB = 2, 4
+    data = make_input(61, R, S * NB, rfi=False, dropped=False)
+    ref = _oracle_pfb_chain(oracle, data)
+    batches = [data[k * S:(k + 1) * S] for k in range(NB)]
+    raw, _, _ = _run_pipelined(lp, batches, R, 0, 2)
+    assert np.array_equal(np.concatenate(raw), ref)
+
+
+@pytest.mark.parametrize("nsets", [1, 2])
+def test_pfb_rfi_mode2_both_streams_bit_exact(oracle, nsets):
+    """(b) RFI mode 2 as benchmarked: RFI bursts, a row with every block flagged (weight 0 for four output rows'
+    window share), a strongly flagged stretch, a dropped frame, three batches (flags of the carried rows are used
+    by the next batch).  Raw AND excised codes bit-exact, weights bit-exact."""
+    lp = libpb()
+    S, NB = 2, 3
+    data = make_input(62, R, S * NB)
+    # four consecutive rows with every block flagged: one output row whose whole window is excised (weight 0, the
+    # +inf convention of the power plane) and neighbours below MIN_WEIGHT
+    for p in range(2):
+        seg = data[3, p, 4 * NFFT:8 * NFFT]
+        seg[:] = np.where((np.arange(seg.size) // 5) % 2 == 0, 220, 36)
+    ref_raw, ref_kur, w, flags = _oracle_pfb_chain_mode2(oracle, data, R)
+    assert flags.sum() > 20 and flags.all(axis=1).sum() >= 5
+    batches = [data[k * S:(k + 1) * S] for k in range(NB)]
+    raw, kur, wts = _run_pipelined(lp, batches, R, 2, nsets)
+    gw = np.concatenate(wts)
+    # pb_fetch reports what tscrunch_weights sees (rows below MIN_WEIGHT as 0)
+    expect_w = np.where(w >= np.float32(0.2), w, np.float32(0))
+    assert np.array_equal(gw.view(np.uint32), expect_w.view(np.uint32)), "window-energy weights differ"
+    assert (w == 0).any() and ((w > 0) & (w < np.float32(0.2))).any() and ((w >= np.float32(0.2)) & (w < 1)).any()
+    assert np.array_equal(np.concatenate(raw), ref_raw), "raw-stream codes differ"
+    assert np.array_equal(np.concatenate(kur), ref_kur), "excised-stream codes differ"
+    assert (ref_kur != ref_raw).any()
+
+
+def test_pfb_fullsize_two_segments_mode2_bit_exact(oracle):
+    """(c) R = 1024 (the production segment: XCD-aware row mapping, 32-row detect chunks), two segments in one
+    call, RFI mode 2, both streams bit-exact against the composed oracle."""
+    lp = libpb()
+    Rf = 1024
+    data = make_input(63, Rf, 2)
+    ref_raw, ref_kur, w, flags = _oracle_pfb_chain_mode2(oracle, data, Rf)
+    raw, kur, wts = _run_pipelined(lp, [data], Rf, 2, 2)
+    assert np.array_equal(raw[0], ref_raw), "raw-stream codes differ"
+    assert np.array_equal(kur[0], ref_kur), "excised-stream codes differ"

@@ -145,12 +145,62 @@ def test_gulps_with_overlap_find_a_pulse_across_the_boundary():
         found = []
         for i in range(0, T, 2048):
             found += g.push(codes[i:i + 2048])
+        assert g.done == T - maxd - g.ov                                    # samples with every boxcar width tried
+        found += g.finish()
         assert g.done == T - maxd                                           # every output sample exactly once
     top_w, top_g = whole[0], max(found, key=lambda c: c["snr"])
     assert abs(top_w["dm"] - dm) <= 4 and abs(top_w["peak_idx"] - t0) <= 4
     assert (top_g["dmi"], top_g["peak_idx"], top_g["tfilt"]) == (top_w["dmi"], top_w["peak_idx"], top_w["tfilt"])
     assert abs(top_g["snr"] / top_w["snr"] - 1) < 0.1                       # (statistics are per gulp)
     assert sum(1 for c in found if c["snr"] > 0.6 * top_g["snr"]) == 1     # once
+
+
+def test_wide_pulse_just_before_a_gulp_boundary_gets_its_full_width():
+    """A 16-sample pulse whose first sample is among the last output samples of a gulp: k_boxcar stops at the end
+    of its block, so inside that gulp only the narrow widths fit.  Those samples are emitted by the NEXT gulp
+    (tail = max_delay + widest - 1 samples), with the same width and position as in a single-block search."""
+    nchan, T, tsamp = 256, 8192, search.TSAMP
+    fch1, foff = 361.94, -0.16
+    kw = dict(nchan=nchan, fch1=fch1, foff=foff, tsamp=tsamp, dm_min=0.0, dm_max=40.0, dm_step=4.0, boxcar_max=16, zap=())
+    with search.Searcher(**dict(kw, max_samples=T)) as s:
+        maxd = s.max_delay
+    gulp = 2048
+    t0 = 2 * gulp - maxd - 6          # six samples before the end of the second gulp's output
+    codes, _ = _plane(91, T, nchan, dm=20.0, t0=t0, width=16, amp=0.45, fch1=fch1, foff=foff, tsamp=tsamp)
+    with search.Searcher(**dict(kw, max_samples=T)) as s:
+        whole = search.candidates_from_peaks(s.peaks(codes, 7.0), s.dms, s.tsamp)[0]
+    assert whole["tfilt"] == 4 and abs(whole["peak_idx"] - t0) <= 3
+    with search.Searcher(**dict(kw, max_samples=gulp + maxd + 64)) as s:
+        g = search.GulpSearch(s, threshold=7.0)
+        found = []
+        for i in range(0, T, gulp):
+            found += g.push(codes[i:i + gulp])
+        found += g.finish()
+        assert g.done == T - maxd
+    top = max(found, key=lambda c: c["snr"])
+    assert (top["tfilt"], top["dmi"]) == (whole["tfilt"], whole["dmi"]) and abs(top["peak_idx"] - whole["peak_idx"]) <= 1
+    assert top["snr"] > 0.9 * whole["snr"]
+
+
+def test_search_without_zap_at_full_block_length():
+    """no zapped channels, nsamp == max_samples and tout a little past a multiple of the 2048-sample
+    tile: lanes past the last output sample must not load (they used to read up to a tile past the last channel's
+    row).  Integer series against NumPy."""
+    nchan, tsamp = 64, search.TSAMP
+    fch1, foff = 361.94, -0.5
+    with search.Searcher(nchan=nchan, max_samples=4096, fch1=fch1, foff=foff, tsamp=tsamp, dm_min=0.0, dm_max=30.0,
+                         dm_step=10.0, boxcar_max=4, zap=()) as s:
+        maxd = s.max_delay
+    T = 2048 + 8 + maxd               # tout = 2056: the second tile has 8 live samples
+    codes, _ = _plane(92, T, nchan, dm=10.0, t0=500, width=2, amp=1.0, fch1=fch1, foff=foff, tsamp=tsamp)
+    with search.Searcher(nchan=nchan, max_samples=T, fch1=fch1, foff=foff, tsamp=tsamp, dm_min=0.0, dm_max=30.0,
+                         dm_step=10.0, boxcar_max=4, zap=()) as s:
+        assert s.max_delay == maxd
+        r = s.run(codes, want_series=True)
+        f = fch1 + foff * np.arange(nchan)
+        delays = np.stack([np.round(4.148808e3 * dm * (f ** -2 - f[0] ** -2) / tsamp).astype(int) for dm in s.dms])
+    series, tout = _numpy_search(codes, nchan, delays, np.zeros(nchan, bool), 3)
+    assert tout == 2056 and np.array_equal(r["series"], series)
 
 
 def test_running_baseline_follows_a_drifting_level():

@@ -481,7 +481,14 @@ static hipError_t submit_stream(pb_handle *h, hipStream_t *out)
 {
     if (h->sets.size() < 2) { *out = h->stream; return hipSuccess; }
     *out = h->s_kur;
-    if (h->last_set == h->cur_set) return hipStreamWaitEvent(h->s_kur, h->ev_alldone, 0);
+    if (h->last_set == h->cur_set) {
+        // refilling the set that was processed last: behind that whole batch -- detect / copy-out (ev_alldone)
+        // and, with taps = 4, the history kernel, which reads the last three rows of d_in on the main stream
+        // AFTER ev_fftdone and is therefore not covered by ev_alldone
+        hipError_t e = hipStreamWaitEvent(h->s_kur, h->ev_alldone, 0);
+        if (e == hipSuccess && h->cfg.taps == 4) e = hipStreamWaitEvent(h->s_kur, h->ev_hist, 0);
+        return e;
+    }
     // hipFFT back end: its kurtosis pass (the last reader of d_in) runs on the MAIN stream, which s_kur is
     // not ordered behind: staging batch k+2 into this set must wait for the latest FFT stage, which is
     // queued behind every earlier reader of this set's input.  (LDS back end: kurtosis and the channeliser
@@ -763,10 +770,25 @@ static int exec_fft(pb_handle *h, int nseg)
     return PB_OK;
 }
 
+// Every plane the configured RFI mode / FFT back end launches kernels on exists in the selected buffer set: a
+// launcher never dereferences a stream's buffers that pb_create did not allocate (modes 0 / 1 have one stream).
+static int check_planes(pb_handle *h)
+{
+    const bool hipfft = h->cfg.fft_backend == PB_FFT_HIPFFT;
+    const bool need_raw = h->cfg.rfi_mode != 1, need_kur = h->cfg.rfi_mode != 0;
+    bool ok = h->d_in && h->d_flags && h->d_wrow && h->d_codes && h->h_codes && h->d_bp;
+    if (need_raw) ok = ok && h->d_Praw && (!hipfft || (h->d_fraw && h->d_Xraw));
+    if (need_kur) ok = ok && h->d_Pkur && (!hipfft || (h->d_fkur && h->d_Xkur));
+    if (h->cfg.keep_ave) ok = ok && h->d_ave;
+    if (h->cfg.taps == 4) ok = ok && h->d_hist_in && h->d_hist_flags && h->d_hist_valid && h->d_tapE;
+    return ok ? PB_OK : fail(h, PB_ESTATE, "pb_process: a buffer of the selected set is missing for this RFI mode / back end");
+}
+
 extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
 {
     if (!h) return PB_EINVAL;
     if (nseg < 1 || nseg > h->S) return fail(h, PB_EINVAL, "pb_process: nseg out of range");
+    if (int rc = check_planes(h)) return rc;
     if (!h->cfg.inject_frb) inject_now = 0;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const bool hipfft = h->cfg.fft_backend == PB_FFT_HIPFFT;

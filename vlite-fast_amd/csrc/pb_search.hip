@@ -106,6 +106,11 @@ __global__ __launch_bounds__(256) void k_dedisperse(const uint8_t *__restrict__ 
 {
     const int dm0 = blockIdx.y * DDM_DB;
     const int t = blockIdx.x * DDM_TILE + threadIdx.x * DDM_SAMPLES;      // 4-byte aligned (tpitch is a multiple of 64)
+    // Lanes past the last output sample of the last tile have nothing to do, and their loads (up to a tile past
+    // tout, plus the delay) would leave the last channel's row -- and, for the last channel, the allocation
+    // (tpitch * nchan + 64 bytes).  No barrier in this kernel: a whole-lane exit is safe.  A live lane reads at
+    // most t + d + 11 <= tout - 1 + max_delay + 11 = nsamp + 10, inside the row's pitch or the 64-byte pad.
+    if (t >= tout) return;
     uint32_t lo[DDM_DB][DDM_SAMPLES / 4], hi[DDM_DB][DDM_SAMPLES / 4];   // packed u16 partial sums: bytes 0,2 / 1,3
     uint32_t acc[DDM_DB][DDM_SAMPLES];
     const int32_t *dl[DDM_DB];
@@ -579,7 +584,7 @@ extern "C" int pb_search_peaks(pb_search *s, const void *codes, int codes_on_dev
     int32_t n = 0;
     SCHK(s, hipMemcpyAsync(&n, s->d_peaks, sizeof n, hipMemcpyDeviceToHost, s->stream));
     SCHK(s, hipStreamSynchronize(s->stream));
-    const int ncopy = n < max_out ? (n < s->max_peaks ? n : s->max_peaks) : max_out;
+    const int ncopy = std::min(std::min((int)n, max_out), s->max_peaks);      // never past the device list
     if (ncopy > 0) SCHK(s, hipMemcpy(peaks, s->d_peaks + 1, (size_t)ncopy * 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
     SCHK(s, hipEventRecord(s->ev[6], s->stream));
     SCHK(s, hipEventSynchronize(s->ev[6]));

@@ -348,22 +348,27 @@ struct FileRing : ReadRing {
             if (want >= 2 * CH) {
                 const int nth = (int)std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency()));
                 std::vector<std::thread> th;
-                std::vector<size_t> got(nth, 0);
+                std::vector<size_t> got(nth, 0), span(nth, 0);
                 const size_t per = ((want / nth) + 4095) & ~(size_t)4095;
                 for (int t = 0; t < nth; ++t)
                     th.emplace_back([&, t]() {
                         size_t a = std::min(want, (size_t)t * per), b = std::min(want, a + per);
+                        span[t] = b - a;
                         while (a < b) {
                             ssize_t r = pread(fd, (char *)buf + a, b - a, pos + (off_t)a);
+                            if (r < 0 && errno == EINTR) continue;
                             if (r <= 0) break;
                             a += (size_t)r;
                             got[t] += (size_t)r;
                         }
                     });
+                for (int t = 0; t < nth; ++t) th[t].join();
+                // only the CONTIGUOUS prefix counts: a piece that came up short (file truncated under us, I/O
+                // error) ends the read there, so that the frame stream is never assembled around a hole
                 size_t total = 0;
                 for (int t = 0; t < nth; ++t) {
-                    th[t].join();
                     total += got[t];
+                    if (got[t] < span[t]) break;
                 }
                 lseek(fd, pos + (off_t)total, SEEK_SET);
                 return (int64_t)total;
@@ -747,8 +752,17 @@ int run(const Args &args)
             log.line(true, "could not open the filterbank files in %s", args.datadir.c_str());
             return 1;
         }
-        if (out_ring) out_ring->write_header(out_hdr);
-        if (co_ring) co_ring->write_header(co_hdr);
+        // a failed ring write is fail-stop, like check_ipcio_write (src/process_baseband.cu:322-332)
+        auto ring_write = [&](WriteRing *r, const void *buf, size_t n) -> int {
+            if (r->write(buf, n)) return 0;
+            fprintf(stderr, "failed ipcio write\n");
+            log.line(true, "Tried to write %lu bytes to psrdada buffer but the write came up short.", (unsigned long)n);
+            return 1;
+        };
+        if ((out_ring && !out_ring->write_header(out_hdr)) || (co_ring && !co_ring->write_header(co_hdr))) {
+            log.line(true, "Could not write the psrdada output header.");
+            return 1;
+        }
         fwrite(sp_hdr.data(), 1, sp_hdr.size(), fb_fp);
         if (fb_kur_fp) fwrite(sp_hdr.data(), 1, sp_hdr.size(), fb_kur_fp);
 
@@ -772,7 +786,7 @@ int run(const Args &args)
             if (args.rfi_mode != 0) PBCHK(pb_fetch_ptr(h, 0, 1, &kur));
             const uint8_t *main_codes = args.rfi_mode != 1 ? raw : kur, *heim_codes = args.rfi_mode != 0 ? kur : raw;
             for (int iseg = 0; iseg < SEG_PER_SEC; ++iseg) {
-                if (co_ring) co_ring->write(heim_codes + iseg * trim, trim);
+                if (co_ring && ring_write(co_ring, heim_codes + iseg * trim, trim)) return 1;
                 fwrite(main_codes + iseg * trim, 1, trim, fb_fp);
                 if (fb_kur_fp) fwrite(kur + iseg * trim, 1, trim, fb_kur_fp);
                 fb_bytes += trim;
@@ -788,9 +802,9 @@ int run(const Args &args)
                 if (integrated_sec == 10) {                                        // the full 10-s buffer, one write
                     std::vector<uint8_t> all;
                     for (auto &b : out_buf) all.insert(all.end(), b.begin(), b.end());
-                    out_ring->write(all.data(), all.size());
-                } else
-                    out_ring->write(out_buf.back().data(), out_buf.back().size());  // then 1 s at a time
+                    if (ring_write(out_ring, all.data(), all.size())) return 1;
+                } else if (ring_write(out_ring, out_buf.back().data(), out_buf.back().size()))  // then 1 s at a time
+                    return 1;
             }
             if (out_buf.size() > 10) out_buf.erase(out_buf.begin());
             prof_write += now() - t0;

@@ -115,6 +115,10 @@ def load():
     L.pb_debug_fetch.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
     L.pb_channelize_f32.argtypes = [vp, fp, C.c_int, C.c_int, fp]
     L.pb_version.restype = C.c_char_p
+    L.pb_host_alloc.argtypes = [C.c_size_t]
+    L.pb_host_alloc.restype = vp              # (a pointer: the default int restype would truncate it)
+    L.pb_host_free.argtypes = [vp]
+    L.pb_host_free.restype = None
     ip = C.POINTER(C.c_int)
     L.pb_search_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_int, ip, C.c_int, C.POINTER(vp)]

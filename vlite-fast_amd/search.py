@@ -120,7 +120,7 @@ class Searcher(object):
                                      buf.ctypes.data_as(C.POINTER(C.c_int32)), max_out, C.byref(n), C.byref(t))
         if rc != 0:
             raise self._lp.PbError("pb_search_peaks failed (%d): %s" % (rc, self._L.pb_search_last_error(self._s).decode()))
-        k = min(n.value, max_out)
+        k = min(n.value, max_out, 1 << 20)        # (the device list holds 2^20 points)
         b = buf[:k]
         return dict(dmi=b[:, 0].copy(), t=b[:, 1].copy(), snr=b[:, 2].copy().view(np.float32), width_log2=b[:, 3].astype(np.uint8),
                     total=n.value, tout=t.value)
@@ -178,7 +178,9 @@ def candidates_from_peaks(pk, dms, tsamp, dm_tol=0.1, sample0=0):
     idm, it, sn, w = pk["dmi"].astype(np.int64), pk["t"].astype(np.int64), pk["snr"], (1 << pk["width_log2"].astype(np.int64))
     if idm.size == 0:
         return []
-    order = np.argsort(-sn, kind="stable")
+    # strongest first; ties by (DM index, sample): the GPU appends points in arrival order, which differs from run
+    # to run, and the grouping below depends on the order
+    order = np.lexsort((it, idm, -sn.astype(np.float64)))
     idm, it, sn, w = idm[order], it[order], sn[order], w[order]
     taken = np.zeros(idm.size, bool)
     cands = []
@@ -196,16 +198,32 @@ def candidates_from_peaks(pk, dms, tsamp, dm_tol=0.1, sample0=0):
 
 class GulpSearch(object):
     """The search over a stream of filterbank samples in gulps, as heimdall runs it (-nsamps_gulp 30720,
-    scripts/start_heimdall_single_antenna:21): every gulp is searched together with the last max_delay
-    samples of the stream before it, so that each output sample is produced exactly once and a pulse
-    whose sweep straddles a gulp boundary is not lost.  push() returns the candidates of the samples that
-    became complete; sample indices count from the start of the stream."""
+    scripts/start_heimdall_single_antenna:21): every gulp is searched together with the last
+    max_delay + widest_boxcar - 1 samples of the stream before it, and of a gulp's output samples only those for
+    which EVERY boxcar width fits inside the gulp are emitted (k_boxcar stops at the end of the block: the last
+    widest - 1 samples have only been tried with the narrow widths); the rest are produced by the next gulp.  So
+    each output sample is produced exactly once, with all widths, and neither a pulse whose sweep straddles a gulp
+    boundary nor a wide one that starts just before it is lost.  push() returns the candidates of the samples that
+    became complete; finish() those of the stream's last widest - 1 samples (narrow widths only: there is no more
+    data); sample indices count from the start of the stream."""
 
     def __init__(self, searcher, threshold=6.0, nbit=8, coincidencer=None, utc_start="1970-01-01-00:00:00", beam=1):
         self.s, self.threshold, self.nbit = searcher, threshold, nbit
         self.tail = np.zeros((0, searcher.nchan), np.uint8)
         self.done = 0                    # output samples produced so far = stream index of the next block's first output
+        self.ov = (1 << (searcher.nbox - 1)) - 1        # widest boxcar - 1
+        self.pending = None              # peaks of the latest gulp's last `ov` output samples (for finish())
         self.coincidencer, self.utc_start, self.beam = coincidencer, utc_start, beam
+
+    def _send(self, cands, first, nsamps):
+        if self.coincidencer:
+            cmod = importlib.import_module(_pkg + ".candidates")
+            host, port = cmod.parse_coincidencer(self.coincidencer)
+            cmod.send_candidates(host, port, self.utc_start, self.beam, cands, first_sample=first, nsamps=nsamps)
+
+    @staticmethod
+    def _subset(pk, sel):
+        return dict(dmi=pk["dmi"][sel], t=pk["t"][sel], snr=pk["snr"][sel], width_log2=pk["width_log2"][sel])
 
     def push(self, block):
         """block: uint8 [nsamp][nchan] (8-bit codes) of NEW samples"""
@@ -213,18 +231,30 @@ class GulpSearch(object):
             raise ValueError("GulpSearch takes unpacked 8-bit samples")
         block = np.asarray(block, np.uint8).reshape(-1, self.s.nchan)
         data = np.concatenate([self.tail, block]) if self.tail.size else block
-        keep = min(self.s.max_delay, data.shape[0])
-        if data.shape[0] - self.s.max_delay < 64:
+        if data.shape[0] - self.s.max_delay < 64 + self.ov:
             self.tail = data                          # not enough yet for one output block
             return []
         pk = self.s.peaks(data, self.threshold, nbit=8)
-        cands = candidates_from_peaks(pk, self.s.dms, self.s.tsamp, sample0=self.done)
-        self.done += pk["tout"]
+        nout = pk["tout"] - self.ov                   # samples with every width tried
+        full = pk["t"] < nout
+        cands = candidates_from_peaks(self._subset(pk, full), self.s.dms, self.s.tsamp, sample0=self.done)
+        self.pending = (self._subset(pk, ~full), self.done, pk["tout"])
+        first = self.done
+        self.done += nout
+        keep = min(self.s.max_delay + self.ov, data.shape[0])
         self.tail = data[data.shape[0] - keep:].copy()
-        if self.coincidencer:
-            cmod = importlib.import_module(_pkg + ".candidates")
-            host, port = cmod.parse_coincidencer(self.coincidencer)
-            cmod.send_candidates(host, port, self.utc_start, self.beam, cands, first_sample=self.done - pk["tout"], nsamps=pk["tout"])
+        self._send(cands, first, nout)
+        return cands
+
+    def finish(self):
+        """end of the stream: candidates of the last widest - 1 output samples"""
+        if self.pending is None:
+            return []
+        pk, sample0, tout = self.pending
+        self.pending = None
+        cands = candidates_from_peaks(pk, self.s.dms, self.s.tsamp, sample0=sample0)
+        self._send(cands, self.done, tout - (self.done - sample0))
+        self.done = sample0 + tout
         return cands
 
 
@@ -280,6 +310,9 @@ def main(argv=None):
             for c in g.push(blk[:blk.size // nchan * nchan].reshape(-1, nchan)):
                 print(candidate_line(c))
                 ntot += 1
+    for c in g.finish():
+        print(candidate_line(c))
+        ntot += 1
     s.close()
     return ntot
 
