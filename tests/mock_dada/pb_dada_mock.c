@@ -36,7 +36,12 @@ struct pb_dada {
     mock_ring *r;
     int mode;
     int in_obs;
+    int how;              /* 0 none, 1 pb_dada_read, 2 pb_dada_read_mt: psrdada refuses to mix them */
+    uint64_t blocks_opened, blocks_closed;
 };
+
+static uint64_t g_block_size = 1 << 20;   /* the mock ring's buffer size (dada_db -b) for block-level reads */
+void pb_dada_mock_set_block_size(uint64_t n) { g_block_size = n ? n : 1; }
 
 /* test control: create / destroy a ring (dada_db -k KEY ... / dada_db -d), mark it shut down */
 int pb_dada_mock_create(uint32_t key)
@@ -97,9 +102,43 @@ int64_t pb_dada_next_header(pb_dada *d, char *dst)
     return PB_DADA_HDR_SIZE;
 }
 
+/* block-level read: the stream is handed out buffer by buffer (g_block_size bytes each, the last one short),
+ * a buffer is "closed" exactly when its last byte has been consumed */
+int64_t pb_dada_read_mt(pb_dada *d, void *buf, uint64_t nbytes, int nthreads)
+{
+    if (!d || d->mode != PB_DADA_READ || !d->in_obs) return -1;
+    if (d->how == 1) return -4;
+    if (nthreads < 1) return -2;
+    d->how = 2;
+    mock_obs *o = &d->r->obs[d->r->robs];
+    uint64_t got = 0;
+    while (got < nbytes && d->r->rpos < o->len) {
+        const uint64_t bstart = d->r->rpos / g_block_size * g_block_size;
+        uint64_t bend = bstart + g_block_size;
+        if (bend > o->len) bend = o->len;
+        if (d->r->rpos == bstart) d->blocks_opened++;
+        uint64_t n = bend - d->r->rpos;
+        if (n > nbytes - got) n = nbytes - got;
+        memcpy((char *)buf + got, o->data + d->r->rpos, n);
+        got += n;
+        d->r->rpos += n;
+        if (d->r->rpos == bend) d->blocks_closed++;
+    }
+    return (int64_t)got;
+}
+
+/* test probe: buffers opened / handed back by block-level reads on this handle */
+void pb_dada_mock_block_counts(pb_dada *d, uint64_t *opened, uint64_t *closed)
+{
+    *opened = d->blocks_opened;
+    *closed = d->blocks_closed;
+}
+
 int64_t pb_dada_read(pb_dada *d, void *buf, uint64_t nbytes)
 {
     if (!d || d->mode != PB_DADA_READ || !d->in_obs) return -1;
+    if (d->how == 2) return -4;
+    d->how = 1;
     mock_obs *o = &d->r->obs[d->r->robs];
     uint64_t left = o->len - d->r->rpos;
     if (nbytes > left) nbytes = left;
@@ -113,6 +152,7 @@ int pb_dada_end_read(pb_dada *d)
     if (!d || d->mode != PB_DADA_READ) return -1;
     if (!d->in_obs) return 0;
     d->in_obs = 0;
+    d->how = 0;
     d->r->robs++;
     return 0;
 }

@@ -43,13 +43,13 @@ def _decls():
 def test_shim_and_mock_define_every_declared_symbol(mock):
     names = _decls()
     assert names == ["pb_dada_close", "pb_dada_end_read", "pb_dada_end_write", "pb_dada_next_header", "pb_dada_open",
-                     "pb_dada_read", "pb_dada_write", "pb_dada_write_header"]
+                     "pb_dada_read", "pb_dada_read_mt", "pb_dada_write", "pb_dada_write_header"]
     shim = open(os.path.join(ROOT, "vlite-fast_amd", "csrc", "pb_dada_shim.c")).read()
     for n in names:
         assert hasattr(mock, n)
         assert re.search(r"\b%s\s*\(pb_dada \*d|\b%s\s*\(uint32_t key" % (n, n), shim), n
-    # the shim is nothing but the reference's psrdada calls
-    for call in ("dada_hdu_create", "dada_hdu_set_key", "dada_hdu_connect", "dada_hdu_lock_read", "ipcbuf_get_next_read",
+    # the shim is nothing but the reference's psrdada calls (+ psrdada's block-level pair for pb_dada_read_mt)
+    for call in ("ipcio_open_block_read", "ipcio_close_block_read","dada_hdu_create", "dada_hdu_set_key", "dada_hdu_connect", "dada_hdu_lock_read", "ipcbuf_get_next_read",
                  "ipcbuf_mark_cleared", "ipcio_read", "dada_hdu_unlock_read", "dada_hdu_lock_write",
                  "ipcbuf_get_next_write", "ipcbuf_mark_filled", "ipcio_write", "dada_hdu_unlock_write"):
         assert call in shim
@@ -86,6 +86,54 @@ def test_ring_roundtrip_and_protocol(mock):
         w.close()
     finally:
         mock.pb_dada_mock_destroy(0x77)
+
+
+def test_block_level_reads_equal_ipcio_reads_and_never_mix(mock, monkeypatch):
+    """pb_dada_read_mt (the ring's filled buffers, handed back when fully consumed, big pieces copied by several
+    threads) returns the same byte stream as pb_dada_read for any request sizes -- frame-sized probes, seconds
+    that straddle buffers, the short last buffer -- and the two are not mixed within an observation."""
+    mock.pb_dada_mock_set_block_size.argtypes = [C.c_uint64]
+    mock.pb_dada_mock_block_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    mock.pb_dada_mock_create(0x51)
+    try:
+        mock.pb_dada_mock_set_block_size(3 * 5032 * 100)             # 1.5 MB buffers
+        stream = (np.arange(10 * 5032 * 100 + 777, dtype=np.uint64) * 2654435761 >> 7).astype(np.uint8)
+        w = dada.PsrdadaRing(0x51, "w", lib=mock)
+        for _ in range(2):
+            w.write_header(_header())
+            w.write(stream)
+            w.end_of_data()
+        # observation 1: block level (default PB_DADA_THREADS = 8)
+        r = dada.PsrdadaRing(0x51, "r", lib=mock)
+        assert r._threads == 8 and r.next_header() is not None
+        got = [r.read(5032)]                                         # the host's first-frame probe
+        big = np.zeros(4 * 5032 * 100, np.uint8)
+        while True:
+            n = r.readinto(big)
+            got.append(big[:n].tobytes())
+            if n < big.size:
+                break
+        assert r.read(10) == b""
+        assert b"".join(got) == stream.tobytes()
+        o, c = C.c_uint64(), C.c_uint64()
+        mock.pb_dada_mock_block_counts(r._d, C.byref(o), C.byref(c))
+        assert o.value == c.value == 4                               # 3 full buffers + the short one, all handed back
+        with pytest.raises(IOError):
+            r._how = 1
+            r.read(8)                                                # ipcio_read after block-level reads: refused
+        r._how = 2
+        r.finish_observation()
+        # observation 2: the reference's ipcio_read only
+        monkeypatch.setenv("PB_DADA_THREADS", "1")
+        r2 = dada.PsrdadaRing(0x51, "r", lib=mock)
+        r2._d, r._d = r._d, None                                     # (same reader handle: the ring has one read position)
+        assert r2._threads == 1 and r2.next_header() is not None
+        assert r2.read(5032) + r2.read(stream.size) == stream.tobytes()
+        r2.finish_observation()
+        r2.close()
+        w.close()
+    finally:
+        mock.pb_dada_mock_destroy(0x51)
 
 
 def test_process_baseband_on_ring_keys(mock, tmp_path, monkeypatch):

@@ -67,3 +67,63 @@ def test_rccl_world1_pipelined_coadd_equals_single_antenna_codes(target):
         h.close()
     finally:
         dist.destroy_process_group()
+
+
+def _sel_and_dig_8b(v):
+    """sel_and_dig_8b (src/pb_kernels.cu:711-735) on a compact plane: float(double(v) / 0.02957 + 127.5), clamped,
+    truncated"""
+    tmp = (v.astype(np.float64) / 0.02957 + 127.5).astype(np.float32)
+    return np.where(tmp <= 0, 0, np.where(tmp >= 255, 255, np.minimum(tmp, 255).astype(np.uint8))).astype(np.uint8)
+
+
+def test_rccl_world1_two_antennas_per_gpu_local_sum_path():
+    """BASELINE configs[3]'s per-GPU shape: TWO antennas batched on the GPU, so the plane that is reduced is the
+    local-sum kernel's output (pb_coadd_local really launches, no coadd-target shortcut), then the RCCL reduce on
+    the coadd stream, the root's non-blocking requantisation with 1 / sqrt(2) and the one-batch-late collection.
+    Expected bytes: sel_and_dig of (plane_0 + plane_1) / sqrt(2) in fp32, from the antennas' own fp32 planes."""
+    import torch
+    import torch.distributed as dist
+    lp = libpb()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29350 + os.getpid() % 300)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        R, S, NSETS, NSTEP, A = 16, 4, 2, 3, 2
+        data = [[make_input(70 + 10 * k + a, R, S) for a in range(A)] for k in range(NSTEP)]
+        h = lp.PbHandle(device=0, nant=A, nbit=8, npol=1, rfi_mode=2, rows_per_seg=R, max_seg=S, keep_ave=True, nsets=NSETS)
+        d_sum = torch.zeros(S * h.ave_per_seg, dtype=torch.float32, device=dev)
+        ts = torch.cuda.Stream(device=dev)
+        h.sync()
+        h.set_coadd_stream(ts.cuda_stream)
+        expect, coadded = [], []
+        for k in range(NSTEP + 1):
+            if k < NSTEP:
+                h.select_set(k % NSETS)
+                for a in range(A):
+                    for s in range(S):
+                        h.submit_planar(a, s, data[k][a][s, 0], data[k][a][s, 1])
+                h.process(S)
+            if k >= 1:
+                # batch k-1 is complete once its bytes are here; its leg is queued one step late (bench.py's order)
+                h.select_set((k - 1) % NSETS)
+                planes = [h.fetch(a, 0, S, raw=False, kur=False, ave=True)["ave_kur"] for a in range(A)]
+                with torch.cuda.stream(ts):
+                    h.coadd_local(S, d_sum.data_ptr())
+                    dist.reduce(d_sum, dst=0, op=dist.ReduceOp.SUM)          # RCCL, on the coadd stream
+                    h.coadd_finish(S, d_sum.data_ptr(), A, blocking=False)
+                ssum = (np.float32(0) + planes[0]) + planes[1]
+                expect.append(_sel_and_dig_8b(ssum * np.float32(1.0 / np.sqrt(2.0))))
+                if k >= 2:
+                    coadded.append(np.array(h.coadd_view(S, age=1), copy=True))
+        coadded.append(np.array(h.coadd_view(S, age=0), copy=True))
+        h.sync()
+        torch.cuda.synchronize()
+        for k in range(NSTEP):
+            assert np.array_equal(coadded[k], expect[k]), "batch %d" % k
+        assert len(set(c.tobytes() for c in coadded)) == NSTEP
+        h.close()
+    finally:
+        dist.destroy_process_group()

@@ -2,7 +2,7 @@
 
 * inject_frb parity: the in-band self test of the reference (src/process_baseband.cu:1231-1251,
   src/pb_kernels.cu:338-391) is bit-exact vs the oracle on small segments;
-* BASELINE config 3 at full size: 8 antennas batched on one GPU, 8 s of synthetic noise with a
+* BASELINE config 3 at full size: 8 antennas batched on one GPU, the config's 10 s of synthetic noise with a
   DM = 500 pc cm^-3, 2 ms, x1.05 pulse; the dedispersed S/N (estimator of
   analysis/loc_step0.py:optimize_pulse, pinned by tests/golden) is in the range the reference
   quotes for a single antenna ("about 25-30", src/process_baseband.cu:1239) and the fp32 coadd of 8
@@ -65,7 +65,7 @@ def _snr(oracle, plane4096, t_pulse):
 def test_config3_dm500_pulse_8_antennas(oracle):
     import torch
     lp = libpb()
-    A, S, NSEC, R = 8, 10, 8, 1024
+    A, S, NSEC, R = 8, 10, 10, 1024          # BASELINE configs[2]: 8 antennas, 10 s
     n = R * 12500
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)

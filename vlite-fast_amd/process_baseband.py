@@ -41,10 +41,26 @@ MC_GROUP, MC_READER_PORT = "224.3.29.71", 20000       # src/multicast.h:14,16
 CMD_QUIT = ord("Q")                                   # src/def.h:6
 LOGDIR = "/home/vlite-master/mtk/logs"                # src/def.h:26
 
-# source allow-lists for `-w 1` (site policy of the reference, src/util.c:91-152)
-ALLOW_NAMES = ("B0329+54", "J0332+54", "B0531+21", "J0534+22", "B2319+60", "J2321+6024", "B0833-45",
-               "J0835-45", "B1237+25", "B1933+16", "R2", "R3")
-ALLOW_IDS = ("18B-405", "19A-331", "SC1046")
+# `-w 1` writes only for the sources a site file lists (site policy, src/util.c:91-152 of the reference; out of the
+# hot path's scope, so it is data, not code: vlite-fast_amd/site/write_allow.txt or $PB_WRITE_ALLOW)
+WRITE_ALLOW_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "site", "write_allow.txt")
+
+
+def load_write_allow(path=None):
+    """-> (NAME substrings, DATAID substrings); both empty when there is no file"""
+    path = path or os.environ.get("PB_WRITE_ALLOW") or WRITE_ALLOW_FILE
+    names, ids = [], []
+    try:
+        with open(path) as f:
+            for line in f:
+                t = line.split("#", 1)[0].split()
+                if len(t) == 2 and t[0] == "name":
+                    names.append(t[1])
+                elif len(t) == 2 and t[0] == "dataid":
+                    ids.append(t[1])
+    except OSError:
+        pass
+    return tuple(names), tuple(ids)
 
 
 def build_parser():
@@ -148,11 +164,12 @@ def test_for_cmd(sock, cmd):
     return cmd in buf
 
 
-def source_allowed(hdr):
+def source_allowed(hdr, allow=None):
+    names, ids = allow if allow is not None else load_write_allow()
     name = hdr.get("NAME", "")
-    if any(n in name for n in ALLOW_NAMES):
+    if any(n in name for n in names):
         return True
-    return any(i in hdr.get("DATAID", "") for i in ALLOW_IDS)
+    return any(i in hdr.get("DATAID", "") for i in ids)
 
 
 def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None, control_sock=None):
