@@ -47,7 +47,7 @@ def kernel_source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "vlite-fast_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if (f.startswith("k_") and f.endswith(".hip")) or f in ("fft_lds.h", "fft_consts.h", "pb_internal.h"):
+        if (f.startswith("k_") and f.endswith(".hip")) or f in ("fft_lds.h", "fft_consts.h", "pb_internal.h", "kurtosis_dev.h"):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
@@ -155,7 +155,9 @@ def measured_traffic(stage, args, taps, A=1):
     import glob
     if args.backend != "lds" or args.rfi_mode != 2 or args.seg_per_step != 10 or A != 1 or args.rfi_frac:
         return None
-    names = {"kurtosis": "k_kurtosis_row", "channelize": "k_channelize_pfb" if taps == 4 else "k_channelize",
+    fused = taps == 1 and args.rfi_mode != 0 and os.environ.get("PB_FUSE_KURTOSIS", "1") != "0"
+    names = {"kurtosis": "k_kurtosis_row",
+             "channelize": "k_channelize_pfb" if taps == 4 else ("k_channelize_kur" if fused else "k_channelize"),
              "detect": "k_detect2"}
     want = names.get(stage)
     best = None
@@ -205,8 +207,8 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
     if coadd is None:
         coadd = world > 1        # the incoherent sum (local sum -> reduce -> requantise on the root) is part of the step
     backend = lp.FFT_LDS if args.backend == "lds" else lp.FFT_HIPFFT
-    NSETS = args.nsets   # 2 = double-buffered batches: the D2H of second k and the host's collection of it overlap
-                         # the kernels of second k+1
+    NSETS = args.nsets   # >= 2: the D2H of second k and the host's collection of it overlap the kernels of the seconds
+                         # after it (3: the second the host waits for was queued two steps ago)
     h = lp.PbHandle(device=local, nant=A, nbit=args.nbit, npol=1, rfi_mode=args.rfi_mode,
                     fft_backend=backend, rows_per_seg=ROWS, max_seg=S, keep_ave=coadd, nsets=NSETS, taps=taps)
     n = h.seg_samples
@@ -386,6 +388,12 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
                             "traffic": measured_traffic(dom, args, taps, A), "avg_launch_ms": round(avg_ms, 4),
                             "algorithmic_bytes_per_launch": per_launch},
                "stage_ms_per_step": {k: round(v[0] / nsteps_timed, 4) for k, v in tm.items() if v[1] > 0}}
+        # the whole step against the same peak: compulsory bytes of every kernel that ran (the channeliser that flags
+        # its own rows reads the voltages once: no separate kurtosis pass, 256 MB per second of data less than round 2)
+        step_bytes = sum(alg[k] for k in stages) * S * A
+        res["roofline"]["pipeline"] = {"algorithmic_bytes_per_step": step_bytes,
+                                       "achieved": round(step_bytes / (dt / steps) / 1e9, 1),
+                                       "frac": round(step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}
     h.close()
     return res
 
@@ -466,7 +474,9 @@ def build_parser():
     ap.add_argument("--rfi-frac", type=float, default=0.0,
                     help="fraction of 500-sample blocks given an impulsive RFI burst (default: clean noise)")
     ap.add_argument("--taps", type=int, default=1, help="1 = rectangular window (reference GPU path), 4 = PFB")
-    ap.add_argument("--nsets", type=int, default=2, help="buffer sets (1 = no batch pipelining)")
+    ap.add_argument("--nsets", type=int, default=3,
+                    help="buffer sets (1 = no batch pipelining; 3 = the host collects batch k - 2 after queuing batch "
+                         "k, so that its wait for a copy-out never keeps the next batch from being queued)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal)")
     ap.add_argument("--share-gpus", action="store_true",
                     help="rehearsal only: let more ranks than there are GPUs run (ranks wrap onto the cards); "

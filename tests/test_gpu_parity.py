@@ -15,18 +15,22 @@ R = 16          # rows per segment in these tests (200 000 samples per pol)
 NSEG = 3
 
 
-def _run_gpu(lp, data, backend, rfi_mode=2, npol=1, nbit=8, **kw):
+def _run_gpu(lp, data, backend, rfi_mode=2, npol=1, nbit=8, debug_keep=True, **kw):
+    """debug_keep=True keeps the per-block statistics, which also selects the two-kernel path (kurtosis pass, then
+    channeliser); False is the production path of the in-library FFT: the channeliser flags its own rows
+    (k_channelize_kur)."""
     nseg = data.shape[0]
     h = lp.PbHandle(nant=1, nbit=nbit, npol=npol, rfi_mode=rfi_mode, fft_backend=backend,
-                    rows_per_seg=R, max_seg=nseg, keep_ave=True, debug_keep=True, **kw)
+                    rows_per_seg=R, max_seg=nseg, keep_ave=True, debug_keep=debug_keep, **kw)
     for s in range(nseg):
         h.submit_planar(0, s, data[s, 0], data[s, 1])
     h.process(nseg)
     out = h.fetch(0, 0, nseg, weights=True, ave=True)
     out["flags"] = [h.debug_fetch(lp.DBG_FLAGS, 0, s) for s in range(nseg)]
-    out["st_pow"] = [h.debug_fetch(lp.DBG_POW, 0, s) for s in range(nseg)] if rfi_mode else None
-    out["st_kur"] = [h.debug_fetch(lp.DBG_KUR, 0, s) for s in range(nseg)] if rfi_mode else None
-    out["st_dag"] = [h.debug_fetch(lp.DBG_DAG, 0, s) for s in range(nseg)] if rfi_mode else None
+    keep = rfi_mode and debug_keep
+    out["st_pow"] = [h.debug_fetch(lp.DBG_POW, 0, s) for s in range(nseg)] if keep else None
+    out["st_kur"] = [h.debug_fetch(lp.DBG_KUR, 0, s) for s in range(nseg)] if keep else None
+    out["st_dag"] = [h.debug_fetch(lp.DBG_DAG, 0, s) for s in range(nseg)] if keep else None
     out["bp"] = h.get_bandpass(0)
     out["trim"], out["ave_per_seg"] = h.trim, h.ave_per_seg
     h.close()
@@ -122,11 +126,18 @@ def test_hipfft_backend_modes(oracle, data, rfi_mode, npol):
 # ---------------------------------------------------------------------------
 # LDS FFT back end: same FFT operation order as the oracle -> everything bit-exact
 
+@pytest.mark.parametrize("keep", [True, False])
 @pytest.mark.parametrize("rfi_mode,npol,nbit", [(2, 1, 8), (2, 1, 4), (2, 1, 2), (0, 1, 8), (1, 1, 8),
                                                  (2, 2, 8), (2, 2, 2)])
-def test_lds_backend_bit_exact(oracle, data, rfi_mode, npol, nbit):
+def test_lds_backend_bit_exact(oracle, data, rfi_mode, npol, nbit, keep):
+    """keep=True: kurtosis kernel + channeliser (statistics kept); keep=False: the channeliser that flags its own rows"""
     lp = libpb()
-    g = _run_gpu(lp, data, lp.FFT_LDS, rfi_mode=rfi_mode, npol=npol, nbit=nbit)
+    g = _run_gpu(lp, data, lp.FFT_LDS, rfi_mode=rfi_mode, npol=npol, nbit=nbit, debug_keep=keep)
+    if rfi_mode:
+        res0, _, _ = oracle_run(oracle, data, R, rfi_mode=rfi_mode, npol=npol, nbit=nbit)
+        for s in range(NSEG):          # flags and weights of whichever kernel computed them
+            nb = g["flags"][s].size
+            assert np.array_equal(g["flags"][s], (res0[s].dag[:nb] > 3.0).astype(np.uint8))
     res, bp_raw, bp_kur = oracle_run(oracle, data, R, rfi_mode=rfi_mode, npol=npol, nbit=nbit)
     names = {0: ("raw",), 1: ("kur",), 2: ("raw", "kur")}[rfi_mode]
     for name in names:
@@ -144,8 +155,9 @@ def test_lds_backend_bit_exact(oracle, data, rfi_mode, npol, nbit):
         assert _same_bits(gk, bp_raw.reshape(2, NCHAN)[:, 2155:])
 
 
+@pytest.mark.parametrize("keep", [True, False])
 @pytest.mark.parametrize("case", ["dropped_segment", "constant_128", "saturated", "one_pol_dead"])
-def test_lds_backend_degenerate_inputs(oracle, case):
+def test_lds_backend_degenerate_inputs(oracle, case, keep):
     """Inputs the live system does meet: a whole segment of dropped frames (zeros -> kurtosis NaN,
     zero power, bandpass initialised from a zero mean), a dead digitiser (constant mid-scale or rail),
     one polarisation missing.  Codes, fp32 planes (NaN bit patterns included) and bandpass state must
@@ -162,7 +174,7 @@ def test_lds_backend_degenerate_inputs(oracle, case):
         d[1, 0, 12500 * 3:12500 * 9] = 255
     else:
         d[:, 1] = 0
-    g = _run_gpu(lp, d, lp.FFT_LDS, rfi_mode=2, npol=1, nbit=8)
+    g = _run_gpu(lp, d, lp.FFT_LDS, rfi_mode=2, npol=1, nbit=8, debug_keep=keep)
     res, bp_raw, bp_kur = oracle_run(oracle, d, R, rfi_mode=2, npol=1, nbit=8)
     for name in ("raw", "kur"):
         refa = np.concatenate([compact_ave(getattr(r, "ave_" + name), R, 1) for r in res])
@@ -182,8 +194,9 @@ def test_lds_backend_degenerate_inputs(oracle, case):
         assert _same_bits(got[m], ref[m])
 
 
+@pytest.mark.parametrize("keep", [True, False])
 @pytest.mark.parametrize("case", ["dropped_segment", "saturated", "odd_rows_dead"])
-def test_lds_backend_degenerate_inputs_excised_only(oracle, case):
+def test_lds_backend_degenerate_inputs_excised_only(oracle, case, keep):
     """RFI mode 1 (the excised stream alone): rows whose every block is flagged get no transform at all, and
     the workgroup then has to request its next row itself -- at an even row (first of a workgroup's two), at
     an odd one, and for whole segments."""
@@ -198,7 +211,7 @@ def test_lds_backend_degenerate_inputs_excised_only(oracle, case):
     else:
         for r in (1, 3, 5):
             d[1, :, 12500 * r:12500 * (r + 1)] = 255
-    g = _run_gpu(lp, d, lp.FFT_LDS, rfi_mode=1, npol=1, nbit=8)
+    g = _run_gpu(lp, d, lp.FFT_LDS, rfi_mode=1, npol=1, nbit=8, debug_keep=keep)
     res, bp_raw, _ = oracle_run(oracle, d, R, rfi_mode=1, npol=1, nbit=8)
     refa = np.concatenate([compact_ave(r.ave_kur, R, 1) for r in res])
     ga = g["ave_kur"]

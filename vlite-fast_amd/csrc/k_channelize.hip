@@ -43,6 +43,7 @@ extern "C" int pb_internal_ch_stamps(unsigned long long *out)
 #define FFT_STAMP(i) do { if (threadIdx.x == CH_STAMP_TID) ch_ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #endif
 #include "fft_lds.h"
+#include "kurtosis_dev.h"
 
 struct ChanArgs {
     const uint8_t *in;      // [A][S][2][seg_samples]
@@ -56,6 +57,12 @@ struct ChanArgs {
     const float2 *postc;    // post[2155..6250], 16-byte aligned copy
     FrbParams frb;          // delays == nullptr: no injection
     int R, rfi_mode, inject_now;
+    // k_channelize_kur only: where the row's flags, weight and mask go, and the D'Agostino constants
+    uint8_t *flags;         // [A][S*R*25]
+    size_t flags_ant_stride;
+    float *wrow_out;
+    uint32_t *rowmask_out;
+    const DagConsts *dag;
 };
 
 // The row's 12500 bytes go to LDS through 16-byte loads (narrow per-lane loads are bound by the address unit,
@@ -101,10 +108,14 @@ __device__ __forceinline__ float div_full_weight(float x)
 // requested by stage_request; mask and wrow may still be in flight (ROLE 0 first needs them after the FFT).
 // next_row >= 0: the bytes of that row (of the same segment and pol) are requested into st as soon as the FFT is
 // done, so that their latency runs under this transform's spectrum step.
-template <int ROLE>
+// FIX: code 0 -> 128 on every staging (the input buffer has not been patched by a kurtosis pass); next_pol: the
+// polarisation of the next transform's row.
+template <int ROLE, bool FIX = false>
 __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int tid, int seg, int row, int pol, int ant,
-                                                RowStage &st, unsigned mask, float wrow, size_t prow, int next_row)
+                                                RowStage &st, unsigned mask, float wrow, size_t prow, int next_row,
+                                                int next_pol = -1)
 {
+    if (next_pol < 0) next_pol = pol;
     FFT_STAMP(0);
     const unsigned o = (unsigned)(row_byte(a, seg, row, pol, ant) & 15);   // recomputed, not carried from the request
     {
@@ -113,7 +124,7 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
         // the input buffer; only RFI mode 0, which has no kurtosis pass, does it here (four per instruction).
         uint4 *stage = (uint4 *)buf;
         const bool last = tid + 768 < (int)((o + PB_NFFT + 15) >> 4);
-        if (a.rfi_mode == 0) {
+        if (FIX || a.rfi_mode == 0) {
             stage[tid] = fix_zero_codes(st.t0);
             stage[tid + 256] = fix_zero_codes(st.t1);
             stage[tid + 512] = fix_zero_codes(st.t2);
@@ -153,7 +164,7 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
     };
     fft6250(v, buf, (const f2 *)a.tw2, (const f2 *)a.tw3, tid, load_tq);
 #ifndef FFT_LEAN
-    if (next_row >= 0) stage_request(a, tid, seg, next_row, pol, ant, st);
+    if (next_row >= 0) stage_request(a, tid, seg, next_row, next_pol, ant, st);
 #endif
 
     // FRB injection window of this row, per channel (inject_frb :361-380)
@@ -205,7 +216,7 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
                                           : make_float4(pw[0] / wrow, pw[1] / wrow, pw[2] / wrow, pw[3] / wrow);
     }
 #ifdef FFT_LEAN
-    if (next_row >= 0) stage_request(a, tid, seg, next_row, pol, ant, st);
+    if (next_row >= 0) stage_request(a, tid, seg, next_row, next_pol, ant, st);
 #endif
 #ifdef CH_STAMP
     if (ROLE == 0 && threadIdx.x == CH_STAMP_TID) {
@@ -299,6 +310,177 @@ __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
     }
 }
 
+// ---- the channeliser that computes the flags of its own row (RFI modes 1 and 2, taps = 1) ----
+// One workgroup = one FFT row of BOTH polarisations: the flag of a 500-sample block is the max over the two pols of
+// the D'Agostino score, so the row's 2 x 25 blocks are reduced first (k_kurtosis_row's phase: the two rows staged in
+// the FFT buffer, the reference's halving tree per block, 50 lanes of double-precision scores, ballot -> mask and
+// weight, also written out for detect and the debug readers), then the transforms of pol 0 and pol 1 follow as in
+// k_channelize, the next transform's bytes requested while the current one is in its spectrum step.  What it saves
+// against kurtosis kernel + channeliser: the second read of every byte (256 MB per second of data), a kernel whose
+// only overlap partner was the previous batch's detect (0.06 ms alone, 0.13 there), and a cross-stream hand-over;
+// the next batch's channeliser then starts straight behind this one and detect runs wholly beside it.
+// The input buffer is NOT patched for code 0 here (nobody reads it again but this workgroup): every staging fixes
+// the codes on the way (FIX).
+__global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
+{
+    __shared__ __attribute__((aligned(16))) f2 buf[M_HALF];
+    int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = blockIdx.x, seg = blockIdx.y, ant = blockIdx.z;
+    const int grow = seg * a.R + row;
+
+    // both rows' bytes: pol 0 stays in registers for the first transform, both go to LDS for the statistics
+    RowStage st;
+    unsigned off0, off1;
+    uint4 *sraw0 = (uint4 *)buf, *sraw1 = (uint4 *)buf + 784;     // 2 x 12 544 B
+    float *s2 = (float *)((uint4 *)buf + 2 * 784), *s4 = s2 + 50, *sdag = s4 + 50;
+    unsigned *smw = (unsigned *)(sdag + 50);                       // [0] mask, [1] weight bits
+    {
+        RowStage sb;
+        stage_request(a, tid, seg, row, 0, ant, st);
+        stage_request(a, tid, seg, row, 1, ant, sb);
+        off0 = (unsigned)(row_byte(a, seg, row, 0, ant) & 15);
+        off1 = (unsigned)(row_byte(a, seg, row, 1, ant) & 15);
+        const bool l0 = tid + 768 < (int)((off0 + PB_NFFT + 15) >> 4), l1 = tid + 768 < (int)((off1 + PB_NFFT + 15) >> 4);
+        sraw0[tid] = fix_zero_codes(st.t0);
+        sraw0[tid + 256] = fix_zero_codes(st.t1);
+        sraw0[tid + 512] = fix_zero_codes(st.t2);
+        if (l0) sraw0[tid + 768] = fix_zero_codes(st.t3);
+        sraw1[tid] = fix_zero_codes(sb.t0);
+        sraw1[tid + 256] = fix_zero_codes(sb.t1);
+        sraw1[tid + 512] = fix_zero_codes(sb.t2);
+        if (l1) sraw1[tid + 768] = fix_zero_codes(sb.t3);
+    }
+    __syncthreads();
+    {
+        // moments of the 50 blocks: exactly k_kurtosis_row's reduction (same leaves, same tree, same sharing of the
+        // cross-lane levels between four blocks)
+        auto leaves = [&](int bi, float &r2, float &r4) __attribute__((always_inline)) {
+            const int pol = bi >= 25 ? 1 : 0, blk = bi - 25 * pol;
+            const uint8_t *sb = (const uint8_t *)(pol ? sraw1 : sraw0) + (pol ? off1 : off0) + blk * PB_NKURTO;
+            float d2[4], d4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = lane + 64 * i;
+                const bool in = t < 250;
+                const int tt = in ? t : 0;
+                f2k u;
+                u.x = (float)sb[tt];
+                u.y = (float)sb[tt + 250];
+                const f2k k128 = {0.0078125f, 0.0078125f}, m1 = {-1.0f, -1.0f};
+                const f2k x = __builtin_elementwise_fma(u, k128, m1);
+                const f2k aa = x * x;
+                const f2k a2 = aa * aa;
+                const float e4 = a2.x + a2.y, e2 = aa.x + aa.y;
+                d4[i] = in ? e4 : 0.f;
+                d2[i] = in ? e2 : 0.f;
+            }
+            r2 = (d2[0] + d2[2]) + (d2[1] + d2[3]);
+            r4 = (d4[0] + d4[2]) + (d4[1] + d4[3]);
+        };
+        const int bi0 = wave * 12 + min(wave, 2), bi1 = bi0 + (wave < 2 ? 13 : 12);
+        int bi = bi0;
+        for (; bi + 4 <= bi1; bi += 4) {
+            float a2, a4, b2, b4, c2, c4, e2, e4;
+            leaves(bi, a2, a4);
+            leaves(bi + 1, b2, b4);
+            leaves(bi + 2, c2, c4);
+            leaves(bi + 3, e2, e4);
+            float ab2 = fold32(a2, b2), ab4 = fold32(a4, b4), ce2 = fold32(c2, e2), ce4 = fold32(c4, e4);
+            float q2 = fold16(ab2, ce2), q4 = fold16(ab4, ce4);
+            q2 = add_row_shl<8>(q2);
+            q4 = add_row_shl<8>(q4);
+            q2 = add_row_shl<4>(q2);
+            q4 = add_row_shl<4>(q4);
+            q2 = add_row_shl<2>(q2);
+            q4 = add_row_shl<2>(q4);
+            q2 = add_row_shl<1>(q2);
+            q4 = add_row_shl<1>(q4);
+            if ((lane & 15) == 0) {
+                const int rowi = lane >> 4;                            // 0: A, 1: C, 2: B, 3: E
+                const int dst = bi + ((rowi & 1) << 1) + (rowi >> 1);
+                s2[dst] = q2;
+                s4[dst] = q4;
+            }
+        }
+        for (; bi < bi1; ++bi) {
+            float r2, r4;
+            leaves(bi, r2, r4);
+            r2 = add_down32(r2);
+            r4 = add_down32(r4);
+            r2 = add_down16(r2);
+            r4 = add_down16(r4);
+            r2 = add_row_shl<8>(r2);
+            r4 = add_row_shl<8>(r4);
+            r2 = add_row_shl<4>(r2);
+            r4 = add_row_shl<4>(r4);
+            r2 = add_row_shl<2>(r2);
+            r4 = add_row_shl<2>(r4);
+            r2 = add_row_shl<1>(r2);
+            r4 = add_row_shl<1>(r4);
+            if (lane == 0) {
+                s2[bi] = r2;
+                s4[bi] = r4;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 50) {
+        const float p = s2[tid] / PB_NKURTO;
+        const float k = s4[tid] / PB_NKURTO / (p * p);
+        sdag[tid] = dag_one(k, *a.dag);
+    }
+    __syncthreads();
+    if (tid < 25) {
+        const float dmax = fmaxf(sdag[tid], sdag[25 + tid]);
+        const bool bad = dmax > 3.0f;  // DAG_THRESH
+        a.flags[(size_t)ant * a.flags_ant_stride + (size_t)grow * PB_BLK_PER_FFT + tid] = bad ? 1 : 0;
+        const uint32_t m = (uint32_t)__ballot(bad);
+        if (tid == 0) {
+            // kur_weights after apply_kurtosis (:292): one 500/12500 per unflagged block, summed left to right
+            const float inc = (float)PB_NKURTO / PB_NFFT;
+            float w = 0.f;
+            for (int k = PB_BLK_PER_FFT - __popc(m); k > 0; --k) w = w + inc;
+            a.wrow_out[(size_t)ant * a.wrow_ant_stride + grow] = w;
+            a.rowmask_out[(size_t)ant * a.wrow_ant_stride + grow] = m;
+            smw[0] = m;
+            smw[1] = __builtin_bit_cast(unsigned, w);
+        }
+    }
+    __syncthreads();
+    const unsigned mask = __builtin_amdgcn_readfirstlane(smw[0]);
+    const float wrow = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(smw[1]));
+    __syncthreads();        // mask and weight are in registers: the transforms may overwrite buf
+
+    const bool all_bad = mask == 0x1ffffffu;
+    const bool second = a.rfi_mode == 1 || (a.rfi_mode == 2 && mask != 0);
+#pragma unroll 1
+    for (int pol = 0; pol < 2; ++pol) {
+        const size_t prow = (size_t)ant * a.p_ant_stride + (((size_t)seg * 2 + pol) * a.R + row) * PB_NCHANOUT;
+        const int after_row = pol == 0 ? row : -1;         // what follows this pol's transforms: pol 1 of the same row
+        if (pol) __syncthreads();   // the previous transform has finished reading buf
+        if (a.rfi_mode != 1) {
+            // what is requested while this transform is in its spectrum step: the same row again for its excised
+            // transform, else pol 1's row
+            const bool again = second && !all_bad;
+            channelize_pass<0, true>(a, buf, tid, seg, row, pol, ant, st, mask, wrow, prow, again ? row : after_row,
+                                     again ? pol : 1);
+            if (!second) continue;
+        }
+        if (all_bad) {
+            for (int c = tid; c < PB_NCHANOUT; c += 256) a.Pkur[prow + c] = __builtin_inff();
+            if (a.rfi_mode == 1 && after_row >= 0) stage_request(a, tid, seg, after_row, 1, ant, st);
+            continue;
+        }
+        if (a.rfi_mode == 2) {
+            __syncthreads();   // the raw pass has finished reading buf
+            asm volatile("" : "+v"(tid));   // no sharing of tid-derived addresses across the two passes
+        }
+        channelize_pass<1, true>(a, buf, tid, seg, row, pol, ant, st, mask, wrow, prow, after_row, 1);
+    }
+}
+
 static bool check_consts(std::string &why)
 {
     // the literals of fft_consts.h must be what libm gives here and in the oracle
@@ -349,6 +531,17 @@ hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now)
     a.R = h->R;
     a.rfi_mode = h->cfg.rfi_mode;
     a.inject_now = inject_now;
+    a.flags = h->d_flags;
+    a.flags_ant_stride = (size_t)h->S * h->nblk_seg;
+    a.wrow_out = h->d_wrow;
+    a.rowmask_out = pb_rowmask(h);
+    a.dag = h->d_dag;
+    if (pb_fused_kurtosis(h)) {
+        // one workgroup per row (both pols): it computes the row's flags itself
+        dim3 gk((unsigned)h->R, (unsigned)nseg, (unsigned)h->A);
+        k_channelize_kur<<<gk, 256, 0, h->stream>>>(a);
+        return hipGetLastError();
+    }
     dim3 grid((unsigned)((h->R + CH_ROWS - 1) / CH_ROWS), (unsigned)(nseg * 2), (unsigned)h->A);
 #ifdef FFT_LEAN
     static const int lean_lds = getenv("PB_LEAN_LDS") ? atoi(getenv("PB_LEAN_LDS")) : M_HALF * 8;

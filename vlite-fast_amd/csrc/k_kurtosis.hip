@@ -15,100 +15,7 @@
 // back end additionally 4 (+4) B/sample of fp32 voltages written.
 #include "pb_internal.h"
 
-typedef float f2k __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ float cvt_sample(unsigned u)
-{
-    return u == 0 ? 0.0f : (float)u / 128 - 1;
-}
-
-// t^(float(1/3)) by Newton cube root in IEEE double: the same operation sequence as
-// orc_powf_third in the oracle, so that flags agree bit for bit (deviation 1).
-__device__ float dev_powf_third(float t)
-{
-    double d = (double)t;
-    unsigned long long bits = (unsigned long long)__double_as_longlong(d);
-    int e = (int)((bits >> 52) & 0x7ff) - 1023;
-    int q = (e >= 0) ? e / 3 : -((-e + 2) / 3);
-    int r = e - 3 * q;
-    bits = (bits & 0x000fffffffffffffULL) | ((unsigned long long)(1023 + r) << 52);
-    double m = __longlong_as_double((long long)bits);
-    double y = 1.0 + (m - 1.0) * (1.0 / 7.0);
-#pragma unroll 1
-    for (int it = 0; it < 8; ++it) {
-        double y2 = y * y;
-        y = y - (y2 * y - m) / (3.0 * y2);
-    }
-    double s = __longlong_as_double((long long)((unsigned long long)(1023 + q) << 52));
-    double z = (y - 1.0) / (y + 1.0);
-    double z2 = z * z;
-    double lny = 2.0 * z * (1.0 + z2 * (1.0 / 3.0 + z2 * (1.0 / 5.0 + z2 * (1.0 / 7.0))));
-    double lnt = (double)(3 * q) * 0.69314718055994531 + 3.0 * lny;
-    const double dexp = (double)(float)(1. / 3) - 1. / 3;
-    return (float)(y * s * (1.0 + dexp * lnt));
-}
-
-__device__ float dag_one(float kur, const DagConsts &c)
-{
-    float dag = 9.0f;  // DAG_INF = DAG_THRESH + DAG_FB_THRESH + 1
-    if (kur != 0.f) {  // true for NaN (all-zero block): t is NaN, t > 0 false, stays DAG_INF
-        float t = (float)(c.one_m_2_over_A / (1. + ((double)kur - 3. - c.mu1) * c.Z3));
-        if (t > 0) dag = fabsf((float)(c.Z1 * (c.Z2 - (double)dev_powf_third(t))));
-    }
-    return dag;
-}
-
-__device__ __forceinline__ float4 cvt4(uint32_t w)
-{
-    float4 f;
-    f.x = cvt_sample(w & 0xff);
-    f.y = cvt_sample((w >> 8) & 0xff);
-    f.z = cvt_sample((w >> 16) & 0xff);
-    f.w = cvt_sample(w >> 24);
-    return f;
-}
-
-__device__ __forceinline__ unsigned fix0(unsigned w)
-{
-    const unsigned t = ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w;   // bit 7 of a byte set <=> byte != 0
-    return w | (~t & 0x80808080u);
-}
-__device__ __forceinline__ uint4 fix0(uint4 q) { return make_uint4(fix0(q.x), fix0(q.y), fix0(q.z), fix0(q.w)); }
-
-// r[lane] += r[lane + s] for s = 8, 4, 2, 1 inside a row of 16 lanes (DPP row_shl: lane i reads lane
-// i + s of its row); only lanes < s of the row hold meaningful sums afterwards, lane 0 the total --
-// the same additions in the same order as the reference's halving tree (kurtosis :60-94).
-// r[lane] += r[lane + 32] (lanes 0..31) and r[lane] += r[lane + 16] (lanes 0..15) with gfx950's lane-swap
-// instructions: one VALU issue each where __shfl_down goes through the LDS crossbar (ds_bpermute, ~100 cycles
-// of latency on a chain of 12-13 dependent block reductions per wave).  v_permlane32_swap a, b exchanges lanes
-// 32..63 of a with lanes 0..31 of b; v_permlane16_swap the odd 16-lane rows of a with the even rows of b.
-__device__ __forceinline__ float add_down32(float r)
-{
-    const unsigned u = __float_as_uint(r);
-    return r + __uint_as_float(__builtin_amdgcn_permlane32_swap(u, u, false, false)[1]);
-}
-__device__ __forceinline__ float add_down16(float r)
-{
-    const unsigned u = __float_as_uint(r);
-    return r + __uint_as_float(__builtin_amdgcn_permlane16_swap(u, u, false, false)[1]);
-}
-// two blocks at once: lanes 0..31 get x[l] + x[l + 32], lanes 32..63 get y[l - 32] + y[l]
-__device__ __forceinline__ float fold32(float x, float y)
-{
-    const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-    return __uint_as_float(p[0]) + __uint_as_float(p[1]);
-}
-// four blocks at once (x rows: A A B B, y rows: C C E E): rows (A, C, B, E), each row l < 16: v[l] + v[l + 16]
-__device__ __forceinline__ float fold16(float x, float y)
-{
-    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-    return __uint_as_float(p[0]) + __uint_as_float(p[1]);
-}
-template <int S> __device__ __forceinline__ float add_row_shl(float r)
-{
-    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x100 + S, 0xf, 0xf, true);
-    return r + __int_as_float(t);
-}
+#include "kurtosis_dev.h"
 
 #ifdef KU_STAMP_ON
 // timing experiments (variant builds only): the clock at the phase boundaries of every workgroup

@@ -39,6 +39,12 @@ static int fail(pb_handle *h, int code, const std::string &msg)
 
 extern "C" const char *pb_version(void) { return "pb_hip 0.1 (gfx950)"; }
 
+bool pb_fused_kurtosis(const pb_handle *h)
+{
+    static const int allow = getenv("PB_FUSE_KURTOSIS") ? atoi(getenv("PB_FUSE_KURTOSIS")) : 1;
+    return allow && h->cfg.fft_backend == PB_FFT_LDS && h->cfg.taps == 1 && h->cfg.rfi_mode != 0 && !h->cfg.debug_keep;
+}
+
 extern "C" void *pb_host_alloc(size_t nbytes)
 {
     void *p = nullptr;
@@ -304,6 +310,9 @@ static int create_impl(pb_handle *h)
     }
     h->dag = make_dag((float)PB_NKURTO);
     h->dag_fb = make_dag((float)PB_NFFT);
+    // (a copy in device memory for the channeliser that flags its own rows: ten fewer scalar registers of arguments)
+    HIPCHK(h, hipMalloc((void **)&h->d_dag, sizeof(DagConsts)));
+    HIPCHK(h, hipMemcpy(h->d_dag, &h->dag, sizeof(DagConsts), hipMemcpyHostToDevice));
     return PB_OK;
 }
 
@@ -348,6 +357,7 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
     h->d_frb_delays = nullptr;
     h->d_hist_in = h->d_hist_flags = h->d_hist_valid = nullptr;
     h->d_tapE = nullptr;
+    h->d_dag = nullptr;
     h->frb_width = 0.f;
     h->frb_amp = 1.f;
     h->d_Xraw = h->d_Xkur = nullptr;
@@ -361,6 +371,7 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
     h->s_kur = nullptr;
     h->ev_fftdone = h->ev_kur = h->ev_alldone = h->ev_hist = nullptr;
     h->last_set = -1;
+    h->staged = false;
     h->d_coadd_target = nullptr;
     h->d_coadd_codes = h->h_coadd_codes = nullptr;
     h->ev_coadd[0] = h->ev_coadd[1] = nullptr;
@@ -406,7 +417,7 @@ extern "C" void pb_destroy(pb_handle *h)
         if (h->h_codes) (void)hipHostFree(h->h_codes);
     }
     void *ptrs[] = {h->d_vdif, h->d_frame_idx, h->d_bp, h->d_frb_delays, h->d_hist_in, h->d_hist_flags,
-                    h->d_hist_valid, h->d_tapE, h->ft.tw2,
+                    h->d_hist_valid, h->d_tapE, h->d_dag, h->ft.tw2,
                     h->ft.tw3, h->ft.post, h->ft.postc, h->ft.taps, h->ft.taps_n};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -481,6 +492,7 @@ static hipError_t submit_stream(pb_handle *h, hipStream_t *out)
 {
     if (h->sets.size() < 2) { *out = h->stream; return hipSuccess; }
     *out = h->s_kur;
+    h->staged = true;          // the next pb_process orders its first kernel behind s_kur
     if (h->last_set == h->cur_set) {
         // refilling the set that was processed last: behind that whole batch -- detect / copy-out (ev_alldone)
         // and, with taps = 4, the history kernel, which reads the last three rows of d_in on the main stream
@@ -495,6 +507,10 @@ static hipError_t submit_stream(pb_handle *h, hipStream_t *out)
     // of this set ran two batches ago behind s_kur -> ev_kur -> main -> ev_fftdone -> s_kur of the batch
     // between, so the order already holds and staging overlaps the running channeliser.)
     if (h->cfg.fft_backend == PB_FFT_HIPFFT && h->last_set >= 0) return hipStreamWaitEvent(h->s_kur, h->ev_fftdone, 0);
+    // Fused kurtosis: no kernel runs on s_kur any more, so nothing orders it behind the channeliser that read this
+    // set's input last (two batches ago, on the main stream).  This set's ev_chan (its detect is done, queued
+    // behind that channeliser) does: it completed while the batch in between was being channelised.
+    if (pb_fused_kurtosis(h) && h->processed > 0) return hipStreamWaitEvent(h->s_kur, h->ev_chan, 0);
     return hipSuccess;
 }
 
@@ -792,26 +808,33 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
     if (!h->cfg.inject_frb) inject_now = 0;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const bool hipfft = h->cfg.fft_backend == PB_FFT_HIPFFT;
-    // this set's previous D2H must have drained before detect overwrites its code buffer
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_det, 0));
+    // What this batch's first kernels overwrite -- the set's flags, weights and power planes -- was last read by the
+    // set's previous detect (ev_chan).  The copy-out of that batch's bytes (ev_det) only has to have drained before
+    // THIS batch's detect overwrites the code buffer: waiting for it here held the channeliser back by ~0.1 ms per
+    // step once the kurtosis pass in front of it was gone (dispatch timeline, profiles/r03_notes.md).
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_chan, 0));
     {
         // The kurtosis pass only needs the raw bytes, and it is a light memory/LDS kernel while
         // detect of the PREVIOUS batch is a latency-bound one that leaves the CUs mostly idle: when
         // the previous batch used another buffer set, run kurtosis on its own stream, released as
         // soon as the previous channeliser has finished, i.e. beside the previous detect.
-        const bool overlap = !hipfft && h->sets.size() >= 2 && h->last_set >= 0 && h->last_set != h->cur_set;
+        const bool fused = pb_fused_kurtosis(h);     // the channeliser flags its own rows: nothing to launch here
+        const bool overlap = !fused && !hipfft && h->sets.size() >= 2 && h->last_set >= 0 && h->last_set != h->cur_set;
         hipStream_t s_main = h->stream;
         hipError_t e = hipSuccess;
         if (overlap) {
             e = hipStreamWaitEvent(h->s_kur, h->ev_fftdone, 0);
-            if (e == hipSuccess) e = hipStreamWaitEvent(h->s_kur, h->ev_det, 0);   // flags / weights of this set free
+            if (e == hipSuccess) e = hipStreamWaitEvent(h->s_kur, h->ev_chan, 0);  // flags / weights of this set free (its detect is done)
             h->stream = h->s_kur;
-        } else if (h->sets.size() >= 2) {
-            // staging went to s_kur: the main stream must see it
+        } else if (h->sets.size() >= 2 && (h->staged || !fused)) {
+            // staging went to s_kur: the main stream must see it.  (Nothing staged since the last call -- the
+            // caller writes the input buffers itself, pb_input_dev -- and nothing queued on s_kur: no event pair,
+            // a cross-stream dependency costs the command processor ~10-25 us even when it is already met.)
             e = hipEventRecord(h->ev_kur, h->s_kur);
             if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->ev_kur, 0);
         }
-        if (e == hipSuccess) {
+        h->staged = false;
+        if (e == hipSuccess && !fused) {
             StageTimer t(h, PB_ST_KURTOSIS);
             e = launch_kurtosis_flag(h, nseg, hipfft);
             // taps = 4: the weights read the history the previous batch left (and the input staged after this
@@ -857,6 +880,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
     if (overlap_detect && h->sets.size() >= 2 && !hipfft) {
         hipStream_t s_main = h->stream;
         hipError_t e2 = hipStreamWaitEvent(h->s_det, h->ev_fftdone, 0);
+        if (e2 == hipSuccess) e2 = hipStreamWaitEvent(h->s_det, h->ev_det, 0);  // this set's previous bytes have left
         if (e2 == hipSuccess) e2 = hipStreamWaitEvent(h->s_det, h->ev_cl, 0);   // planes of this set were summed
         h->stream = h->s_det;
         if (e2 == hipSuccess) {
@@ -883,6 +907,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         return PB_OK;
     }
     {
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_det, 0));  // this set's previous bytes have left
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_cl, 0));   // planes of this set were summed
         StageTimer t(h, PB_ST_DETECT);
         HIPCHK(h, launch_detect(h, nseg, inject_now));

@@ -94,12 +94,14 @@ struct pb_handle {
     hipEvent_t ev_fftdone, ev_kur, ev_alldone;
     hipEvent_t ev_hist;    // taps = 4: the batch's last rows and flags have been kept for the next one
     int last_set;          // buffer set of the previous pb_process (-1: none)
+    bool staged;           // input has been queued on s_kur since the last pb_process
     uint8_t *d_coadd_codes, *h_coadd_codes;   // [2][S*trim] coadded bytes (device / pinned), lazily
     hipEvent_t ev_coadd[2];
     hipStream_t s_coadd;   // stream of pb_coadd_local / pb_coadd_finish (nullptr: the main stream)
     int coadd_slot, coadd_last;
     FftTables ft;
     DagConsts dag, dag_fb;   // D'Agostino constants for N = 500 (blocks) and N = 12500 (FFT rows, K4)
+    DagConsts *d_dag;        // dag in device memory
     std::map<long, hipfftHandle> plans;
 
     bool profile;
@@ -109,6 +111,11 @@ struct pb_handle {
     std::vector<hipEvent_t> ev_pool;     // free events
     std::string err;
 };
+
+// The channeliser computes the kurtosis flags of its own rows (k_channelize_kur) instead of a kurtosis pass in
+// front of it: in-library FFT, rectangular window, an RFI mode that flags, no statistics kept.  PB_FUSE_KURTOSIS=0
+// keeps the two kernels (timing experiments).
+bool pb_fused_kurtosis(const pb_handle *h);
 
 // row flag masks (bit r = kurtosis block r of the row is flagged), written by k_kurtosis_row behind the weights
 static inline uint32_t *pb_rowmask(pb_handle *h) { return (uint32_t *)(h->d_wrow + (size_t)h->A * h->S * h->R); }
