@@ -1,7 +1,7 @@
 #!/bin/bash
-# Run ON THE GPU BOX: one bench line per secondary mode -> gpurun_out/r2/modes.jsonl
-out=${1:-gpurun_out/r2/modes.jsonl}; mkdir -p $(dirname $out); rm -f $out
-run() { echo "== $*" >&2; timeout -k 10 200 python bench.py --no-cpu-baseline --no-extras --steps 40 --warmup 5 "$@" 2>/dev/null | python -c "
+# Run ON THE GPU BOX: one bench line per secondary mode -> gpurun_out/r3/modes.jsonl
+out=${1:-gpurun_out/r3/modes.jsonl}; mkdir -p $(dirname $out); rm -f $out
+run() { echo "== $*" >&2; timeout -k 10 200 python bench.py --no-cpu-baseline --no-extras --steps 40 --warmup 5 --regions 3 "$@" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); d['args']='$*'; print(json.dumps(d))" >> $out; }
 run
