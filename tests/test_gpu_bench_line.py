@@ -1,0 +1,52 @@
+"""The driver's contract on the line bench.py prints (the prompt's (4)): one JSON object with the metric, the
+whole-job value, cold and sustained timing with spread, a `roofline` object for the dominant kernel measured with
+hipEvents inside the timed region, and a `cpu_baseline` object on rank 0 at N = 1.  A short run of the real
+script on the GPU box."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags, timeout=600):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line"
+    return json.loads(lines[0])
+
+
+def test_bench_line_fields_and_consistency():
+    d = _run("--steps", "6", "--warmup", "2", "--regions", "2", "--no-extras")
+    assert d["metric"].startswith("Msamp/s/antenna") and d["unit"] == "Msamp/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "configs[1]" in d["config"]["workload"] and "model" not in d["config"]
+    # value = dual-pol samples of one second / median region
+    assert abs(d["value"] - 128e6 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+    tr = d["timed_regions"]
+    assert tr["n"] == 2 and tr["ms_per_step_min"] <= d["ms_per_step"] <= tr["ms_per_step_max"]
+    assert d["ms_per_step_cold"] > 0 and d["precondition_steps"] == 100
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-2
+    assert r["avg_launch_ms"] <= d["ms_per_step"] * 1.05            # a kernel of the step cannot outlast the step
+    assert 0.05 < r["frac"] < 1.0 and 0.05 < r["pipeline"]["frac"] < 1.0
+    assert r["kernel"] == "channelize" and "kurtosis" not in d["stage_ms_per_step"]      # the channeliser flags its own rows
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Msamp/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert d["value"] / c["value"] > 50                                # (reported only; sanity of units)
+
+
+def test_bench_two_kernel_path_still_reports_kurtosis_stage():
+    env = dict(os.environ, PB_FUSE_KURTOSIS="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--regions", "1",
+                        "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.strip().splitlines() if l.startswith("{")][0])
+    assert set(d["stage_ms_per_step"]) >= {"kurtosis", "channelize", "detect"} and "cpu_baseline" not in d
