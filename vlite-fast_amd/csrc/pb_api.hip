@@ -213,6 +213,14 @@ static int create_impl(pb_handle *h)
         // priority so that its workgroups slot in between the channeliser's as CUs free up
         int lo = 0, hi = 0;
         HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        // timing experiments: PB_DET_CUS=n confines detect to n CUs of every 32 (a CU mask on its stream), so that
+        // its workgroups pack three to a CU there instead of taking one channeliser slot on every CU
+        const int det_cus = getenv("PB_DET_CUS") ? atoi(getenv("PB_DET_CUS")) : 0;
+        if (det_cus > 0 && det_cus < 32) {
+            uint32_t mask[8];
+            for (int i = 0; i < 8; ++i) mask[i] = (1u << det_cus) - 1u;
+            HIPCHK(h, hipExtStreamCreateWithCUMask(&h->s_det, 8, mask));
+        } else
         HIPCHK(h, hipStreamCreateWithPriority(&h->s_det, hipStreamNonBlocking, hi));
     }
     HIPCHK(h, hipStreamCreateWithFlags(&h->s_kur, hipStreamNonBlocking));
