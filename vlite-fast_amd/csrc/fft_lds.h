@@ -331,6 +331,23 @@ __device__ __forceinline__ void read_z_pairs(const f2 *buf, int k0, f2 (&za)[4],
     zb[3] = mk2(zb32.x, zb32.y);
 }
 
+// Power-plane stores.  PB_NT_STORES: as streaming (non-temporal) stores -- 671 MB per launch of planes that
+// nobody on this die reads again pass through a 4-MB L2 and push out the rows' bytes that a workgroup requests a
+// second time 20 us later.
+#ifndef PB_NT_STORES
+#define PB_NT_STORES 1
+#endif
+__device__ __forceinline__ void store_plane4(float *p, float a, float b, float c, float d)
+{
+    typedef float f4s __attribute__((ext_vector_type(4)));
+    const f4s v = {a, b, c, d};
+#if PB_NT_STORES
+    __builtin_nontemporal_store(v, (f4s *)p);
+#else
+    *(f4s *)p = v;
+#endif
+}
+
 __device__ __forceinline__ float cvt_sample_c(unsigned u) { return u == 0 ? 0.0f : (float)u / 128 - 1; }
 
 // convertarray (src/pb_kernels.cu:23-33) on packed codes.  u / 128 and the subtraction of 1 are both

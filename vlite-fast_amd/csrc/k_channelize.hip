@@ -207,13 +207,17 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
         }
         // the excised plane carries pow / w (detect_and_normalize3 :452,:481), so that the
         // serial bandpass recurrence downstream has no division in it
-        if (ROLE == 0) *(float4 *)(P0 + c4) = make_float4(pw[0], pw[1], pw[2], pw[3]);
+        if (ROLE == 0) store_plane4(P0 + c4, pw[0], pw[1], pw[2], pw[3]);
         if (ROLE == 1)
-            *(float4 *)(P0 + c4) = make_float4(pw[0] / wrow, pw[1] / wrow, pw[2] / wrow, pw[3] / wrow);
+            store_plane4(P0 + c4, pw[0] / wrow, pw[1] / wrow, pw[2] / wrow, pw[3] / wrow);
         else if (also_kur)
-            *(float4 *)(P1 + c4) = full_w ? make_float4(div_full_weight(pw[0]), div_full_weight(pw[1]),
-                                                        div_full_weight(pw[2]), div_full_weight(pw[3]))
-                                          : make_float4(pw[0] / wrow, pw[1] / wrow, pw[2] / wrow, pw[3] / wrow);
+        {
+            if (full_w)
+                store_plane4(P1 + c4, div_full_weight(pw[0]), div_full_weight(pw[1]), div_full_weight(pw[2]),
+                             div_full_weight(pw[3]));
+            else
+                store_plane4(P1 + c4, pw[0] / wrow, pw[1] / wrow, pw[2] / wrow, pw[3] / wrow);
+        }
     }
 #ifdef FFT_LEAN
     if (next_row >= 0) stage_request(a, tid, seg, next_row, next_pol, ant, st);
