@@ -12,6 +12,12 @@
 //     w(g) = sum_{j,b unflagged and present} E[j][b] / sum_{j,b} E[j][b],  E[j][b] = sum_{m in b} taps[j][m]^2.
 // Parity: spectra vs polyphase_filterbank golden (tests, 2e-6), whole chain vs the oracle's kernels
 // composed around the same fp32 FIR (bit-exact, RFI mode 0); the weight definition has no reference.
+// ordinary (L2-allocating) stores of the power planes here: with non-temporal ones this kernel is 6 % faster alone
+// (0.68 against 0.73 ms per launch) and the pipeline 3 % slower (1.02 against 0.995 ms per step: detect's reads of
+// the planes then come from further away), and the step is what counts (profiles/r03_notes.md)
+#ifndef PB_NT_STORES
+#define PB_NT_STORES 0
+#endif
 #include "fft_lds.h"
 
 #ifndef PFB_DBG
