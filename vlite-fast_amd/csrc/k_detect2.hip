@@ -51,6 +51,9 @@ struct Detect2Args {
     float scale, oms, tscale;
 };
 
+#ifndef D2_LOAD_AUX
+#define D2_LOAD_AUX 0              // cache-policy bits of the plane loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
 #ifndef D2_DEPTH
 #define D2_DEPTH 2                 // chunks of power loads in flight per workgroup
 #endif
@@ -288,7 +291,7 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
             for (int i = 0; i < LPC; ++i)
                 __builtin_amdgcn_global_load_lds(
                     (const void __attribute__((address_space(1))) *)(src + (size_t)(4 * i) * PB_NCHANOUT),
-                    (void __attribute__((address_space(3))) *)&s_p[cu.slot][4 * i][0], 16, 0, 0);
+                    (void __attribute__((address_space(3))) *)&s_p[cu.slot][4 * i][0], 16, 0, D2_LOAD_AUX);
         };
         Cursor cu;
         cu.init(0, cps);
