@@ -70,8 +70,10 @@ typedef struct pb_config {
     int32_t max_seg;        /* segments staged per pb_process call (>= 1) */
     int32_t inject_frb;     /* -i   :399-401, :711-718 */
     int32_t keep_ave;       /* also keep the fp32 pre-quantisation planes (coadd input) */
-    int32_t debug_keep;     /* keep kurtosis statistics for pb_debug_fetch */
-    int32_t nsets;          /* buffer sets for batch pipelining (1 = none, 2 = double-buffered) */
+    int32_t debug_keep;     /* keep kurtosis statistics for pb_debug_fetch (selects the kurtosis kernel + channeliser
+                             * pair; without it the in-library-FFT channeliser flags its own rows: same results) */
+    int32_t nsets;          /* buffer sets for batch pipelining, 1..8 (1 = none, 2 = double-buffered, 3 = the host
+                             * collects the batch queued two calls ago) */
 } pb_config;
 
 typedef struct pb_sizes {
@@ -168,9 +170,12 @@ int pb_set_frb_params(pb_handle *h, float dm, float width_rows, float amp);
 int pb_fetch(pb_handle *h, int ant, int seg0, int nseg, uint8_t *raw_codes, uint8_t *kur_codes,
              float *weights, float *ave_raw, float *ave_kur);
 /* Pipelining across batches (nsets >= 2): every submit / process / fetch / debug call acts on
- * the SELECTED buffer set.  Typical loop: select(k&1); submit; process; select((k-1)&1); fetch.
- * Detect + D2H of one set run on a second stream while the next set's kurtosis + channeliser
- * run on the first; the bandpass state is shared and advances in pb_process order. */
+ * the SELECTED buffer set.  Typical loop: select(k % n); submit; process; select((k-1) % n); fetch
+ * (n = 3: fetch batch k-2, whose bytes have arrived, so that the wait never delays queuing batch k+1).
+ * Detect + D2H of one set run on streams of their own while the next set's channeliser (and, with
+ * taps = 4 / the hipFFT back end / debug_keep, its kurtosis pass) runs on the first; the bandpass state
+ * is shared and advances in pb_process order.  A set's input may be restaged once its previous detect
+ * is done; its filterbank bytes must have been fetched before the pb_process after next on that set. */
 int pb_select_set(pb_handle *h, int set);
 /* zero-copy view of the selected set's filterbank bytes in pinned host memory (valid until the
  * next pb_process on that set): [max_seg][code_bytes_per_seg] of antenna ant, stream 0/1 */
