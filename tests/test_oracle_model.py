@@ -181,3 +181,35 @@ def test_numpy_model_of_kurtosis_flags_and_weights_agrees_with_the_c_oracle(orac
         t1 = (1 - 2.0 / A) / (1 + xs1 * np.sqrt(2.0 / (A - 4.0)))
         assert abs((1 - 2.0 / (9 * A) - np.cbrt(t1)) / np.sqrt(2.0 / (9 * A)) - zk) < 1e-9
     assert nflag > 20
+
+
+def test_numpy_model_of_the_4_and_2_bit_packers_agrees_with_the_c_oracle(oracle):
+    """sel_and_dig_4b :672-708 (two samples per byte, the first in the low nibble) and sel_and_dig_2b :633-669 (four
+    per byte, the first in the low bits; thresholds -0.6109 / 0.3970 / 1.4050), one and two polarisations
+    ([time][pol][channel] byte order for npol 2): vectorised NumPy against the oracle, values kept away from the
+    decision levels by construction so that the comparison is exact."""
+    L = oracle.lib()
+    fp, u8p = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+    rng = np.random.default_rng(11)
+    ntime = 4
+    for npol in (1, 2):
+        ave = (rng.standard_normal((npol, ntime, NCHAN)) * 1.3).astype(np.float32)
+        # keep clear of the 2-bit levels and of the 4-bit step edges
+        for lvl in (-0.6109, 0.3970, 1.4050):
+            ave[np.abs(ave - lvl) < 1e-3] += 0.01
+        t4 = ave.astype(np.float64) / 0.3188 + 7.5
+        ave[np.abs(t4 - np.round(t4)) < 1e-3] += 0.002
+        sel = ave[:, :, CHANMIN:CHANMIN + NCHANOUT].transpose(1, 0, 2).reshape(-1)       # [time][pol][channel]
+        # 4 bits
+        q4 = np.clip(np.floor(sel.astype(np.float64) / 0.3188 + 7.5), 0, 15).astype(np.uint8)
+        exp4 = (q4[0::2] | (q4[1::2] << 4)).astype(np.uint8)
+        got4 = np.zeros(exp4.size, np.uint8)
+        L.orc_sel_and_dig_4b(ave.ctypes.data_as(fp), got4.ctypes.data_as(u8p), got4.size, npol, ntime)
+        assert np.array_equal(got4, exp4)
+        # 2 bits
+        q2 = np.digitize(sel.astype(np.float64), [-0.6109, 0.3970, 1.4050]).astype(np.uint8)
+        exp2 = (q2[0::4] | (q2[1::4] << 2) | (q2[2::4] << 4) | (q2[3::4] << 6)).astype(np.uint8)
+        got2 = np.zeros(exp2.size, np.uint8)
+        L.orc_sel_and_dig_2b(ave.ctypes.data_as(fp), got2.ctypes.data_as(u8p), got2.size, npol, ntime)
+        assert np.array_equal(got2, exp2)
+        assert len(np.unique(q2)) == 4 and q4.min() == 0 and q4.max() == 15
