@@ -351,3 +351,35 @@ def test_pipelined_buffer_sets_hipfft_backend(oracle):
         ref = np.concatenate([getattr(r, name) for r in res]).astype(int)
         d = np.abs(np.concatenate(got).astype(int) - ref)
         assert d.max() <= 1 and (d != 0).mean() < 2e-3
+
+
+@pytest.mark.parametrize("nsets,rfi_mode", [(2, 2), (3, 2), (2, 1)])
+def test_pipelined_sets_with_32_row_chunks_bit_exact(oracle, nsets, rfi_mode):
+    """R = 64: detect's 32-row chunks, and -- pipelined, with the channeliser that flags its own rows -- its
+    three-chunks-in-flight ring (launch_detect_pow picks DEPTH 3 there, 2 everywhere else); five batches through
+    reused buffer sets, collected nsets - 1 batches late, against the oracle's serial run."""
+    lp = libpb()
+    Rr, nseg, nb = 64, 2, 5
+    data = make_input(37, Rr, nseg * nb)
+    got = {"raw": [], "kur": []}
+
+    def collect(h, b):
+        h.select_set(b % nsets)
+        o = h.fetch(0, 0, nseg, raw=rfi_mode != 1, kur=rfi_mode != 0)
+        for k in got:
+            got[k].append(o[k])
+
+    with lp.PbHandle(nbit=8, rfi_mode=rfi_mode, rows_per_seg=Rr, max_seg=nseg, nsets=nsets) as h:
+        for b in range(nb):
+            h.select_set(b % nsets)
+            for s in range(nseg):
+                h.submit_planar(0, s, data[b * nseg + s, 0], data[b * nseg + s, 1])
+            h.process(nseg)
+            if b >= nsets - 1:
+                collect(h, b - (nsets - 1))
+        for b in range(max(0, nb - (nsets - 1)), nb):
+            collect(h, b)
+    res, _, _ = oracle_run(oracle, data, Rr, rfi_mode=rfi_mode)
+    if rfi_mode != 1:
+        assert np.array_equal(np.concatenate(got["raw"]), np.concatenate([r.codes_raw for r in res]))
+    assert np.array_equal(np.concatenate(got["kur"]), np.concatenate([r.codes_kur for r in res]))

@@ -5,7 +5,7 @@
 // but split so that only what is truly serial in time runs serially.  One 384-thread workgroup = 32
 // channels x 2 pols of one stream, chunks of T rows, one barrier per chunk step:
 //
-//   loader (wave 4): streams the power plane into an LDS ring D2_DEPTH chunks ahead with
+//   loader (wave 4): streams the power plane into an LDS ring DEPTH chunks ahead with
 //            global_load_lds_dwordx4 (LDS-DMA, no registers);
 //   A  (wave 0, lane = (pol, channel)): the running-bandpass recurrence  bp = s*p + (1-s)*bp  with the 11x
 //            clip of the excised stream, for chunk k; leaves bp after every row in LDS;
@@ -36,6 +36,8 @@
 //   rows of weight 0 arrive as +inf: inf > bp*11 keeps the bandpass (:474-476), phase B zeroes x from w.
 //
 // HBM traffic: the power planes (4 B per row x channel x pol x stream) once; outputs 1/64 of it.
+#include <cstdlib>
+
 #include "pb_internal.h"
 
 struct Detect2Args {
@@ -54,11 +56,20 @@ struct Detect2Args {
 #ifndef D2_LOAD_AUX
 #define D2_LOAD_AUX 0              // cache-policy bits of the plane loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
 #endif
-#ifndef D2_DEPTH
-#define D2_DEPTH 2                 // chunks of power loads in flight per workgroup
+#ifndef D2_PRIO_B
+#define D2_PRIO_B 0                // wave priority of the loader and phase-B waves (the recurrence wave runs at 3)
 #endif
-#define D2_NSLOT (D2_DEPTH + 2)    // LDS ring slots: B takes chunk k-1 into registers during step k, A reads k,
-                                   // k+1 .. k+D2_DEPTH landed / in flight  (4 x 8 KB + 16 KB of bp = 49 KB:
+// DEPTH (template parameter): chunks of power loads in flight per workgroup; LDS ring slots = DEPTH + 2: B takes chunk
+// k-1 into registers during step k, A reads k, k+1 .. k+DEPTH landed / in flight.  DEPTH 2: 4 x 8 KB + 16 KB of bp =
+// 49 KB; DEPTH 3: 57 KB -- either way a detect workgroup takes the place of exactly one 50-KB channeliser workgroup
+// of the next batch.  Beside the channeliser that flags its own rows (detect runs wholly beside it) three chunks in
+// flight make the step 1 - 3 % shorter with one antenna per GPU (0.634 -> 0.617 ms on one box, 0.636 -> 0.628 on
+// another, alternating runs); with two antennas per GPU, and beside the kurtosis pass and the PFB channeliser, two
+// are 1 - 1.5 % better (0.986 against 1.002 ms): launch_detect_pow picks.
+#ifndef D2_DEPTH_OVERLAPPED
+#define D2_DEPTH_OVERLAPPED 3
+#endif
+#define D2_NSLOT (DEPTH + 2)       // (4 x 8 KB + 16 KB of bp = 49 KB at DEPTH 2:
                                    // a detect workgroup fits beside two channeliser workgroups of the next batch)
 #define D2_THREADS 384
 #define D2_WAVE_A 0
@@ -236,7 +247,7 @@ __device__ __forceinline__ void phase_b_finish(const Detect2Args &a, const BStat
 
 // Position of one pipeline stage: chunk index and what is derived from it, advanced with adds and compares
 // (a scalar division or remainder costs the wave tens of issue slots per step)
-struct Cursor {
+template <int DEPTH> struct Cursor {
     int c, slot, seg, rb;      // chunk, ring slot (c mod NSLOT), segment, chunk within the segment
     __device__ __forceinline__ void init(int c0, int cps)
     {
@@ -259,7 +270,7 @@ struct Cursor {
 
 }  // namespace
 
-template <int T, bool KUR, int NPOL, int NBIT>
+template <int T, bool KUR, int NPOL, int NBIT, int DEPTH>
 __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[T][64], float4 (*s_u)[T / 4][64],
                                              float (*s_u0)[64], float (*s_w)[T])
 {
@@ -283,9 +294,12 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
 
     if (wave == D2_WAVE_L) {
         // ---- loader: lane -> (row in group of 4, pol, 4 channels)
+#if D2_PRIO_B
+        __builtin_amdgcn_s_setprio(D2_PRIO_B);
+#endif
         const int ld_row = lane >> 4, ld_pol = (lane >> 3) & 1, ld_c = cg * 32 + (lane & 7) * 4;
         const size_t loff = (size_t)ld_pol * pol_stride + (size_t)ld_row * PB_NCHANOUT + ld_c;
-        auto issue = [&](const Cursor &cu) {
+        auto issue = [&](const Cursor<DEPTH> &cu) {
             const float *src = Pant + (size_t)cu.seg * seg_stride + (size_t)(cu.rb * T) * PB_NCHANOUT + loff;
 #pragma unroll
             for (int i = 0; i < LPC; ++i)
@@ -293,23 +307,23 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
                     (const void __attribute__((address_space(1))) *)(src + (size_t)(4 * i) * PB_NCHANOUT),
                     (void __attribute__((address_space(3))) *)&s_p[cu.slot][4 * i][0], 16, 0, D2_LOAD_AUX);
         };
-        Cursor cu;
+        Cursor<DEPTH> cu;
         cu.init(0, cps);
-        for (int kk = 0; kk < D2_DEPTH && kk < nchunk; ++kk) {
+        for (int kk = 0; kk < DEPTH && kk < nchunk; ++kk) {
             issue(cu);
             cu.next(cps);
         }
-        if (nchunk > D2_DEPTH - 1) wait_vmcnt<(D2_DEPTH - 1) * LPC>();     // chunk 0 has landed
+        if (nchunk > DEPTH - 1) wait_vmcnt<(DEPTH - 1) * LPC>();     // chunk 0 has landed
         else wait_vmcnt<0>();
         step_barrier();
         for (int k = 0; k < nstep; ++k) {
             if (cu.c < nchunk) {
-                issue(cu);                              // chunk k + D2_DEPTH
+                issue(cu);                              // chunk k + DEPTH
                 cu.next(cps);
 #ifdef D2_STAMP
                 const long long tw0 = D2_NOW();
 #endif
-                wait_vmcnt<(D2_DEPTH - 1) * LPC>();     // chunk k + 1 has landed
+                wait_vmcnt<(DEPTH - 1) * LPC>();     // chunk k + 1 has landed
 #ifdef D2_STAMP
                 clk.extra += D2_NOW() - tw0;
 #endif
@@ -329,7 +343,7 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
         // row weights of the next chunk are requested one step ahead (rows of chunk k are the contiguous
         // wrow[k*T .. k*T+T-1]) and staged in LDS for phase B
         float wv_next = (KUR && lane < T && nchunk > 0) ? wrow[lane] : 1.f;
-        Cursor cu;
+        Cursor<DEPTH> cu;
         cu.init(0, cps);
         step_barrier();
         for (int k = 0; k < nstep; ++k) {
@@ -407,6 +421,9 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
         *bpp = bp;
     } else if (bi >= 0) {
         // ---- B.  wave -> (chunk parity, half of the lane tasks); lane task -> (8-row group, channel), both pols
+#if D2_PRIO_B
+        __builtin_amdgcn_s_setprio(D2_PRIO_B);
+#endif
         const int par = bi >> 1, idxB = (bi & 1) * 64 + lane;
         const int g = idxB >> 5, ch = idxB & 31;
         const bool active = g < NG;
@@ -415,7 +432,7 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
         float *ave = a.ave ? a.ave + ((size_t)ant * 2 + stream) * a.S * a.ave_per_seg : nullptr;
         if (a.ave_target && ant == 0 && stream == a.target_stream) ave = a.ave_target;
         BState<NPOL> bs;
-        Cursor cu;                       // this wave's next chunk: those of its parity
+        Cursor<DEPTH> cu;                // this wave's next chunk: those of its parity
         cu.init(0, cps);
         if (par) cu.next(cps);
         step_barrier();
@@ -465,7 +482,7 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
 }
 
 // MODE = rfi_mode: 0 raw stream only, 1 excised only, 2 both (blockIdx.y picks the stream)
-template <int T, int NPOL, int NBIT, int MODE>
+template <int T, int NPOL, int NBIT, int MODE, int DEPTH>
 __global__ __launch_bounds__(D2_THREADS) void k_detect2(Detect2Args a)
 {
     // ring of power chunks filled by LDS-DMA (global_load_lds_dwordx4: no registers, no VALU)
@@ -475,29 +492,29 @@ __global__ __launch_bounds__(D2_THREADS) void k_detect2(Detect2Args a)
     __shared__ __attribute__((aligned(16))) float4 s_u[2][T / 4][64];
     __shared__ float s_u0[2][64];
     __shared__ float s_w[3][T];
-    if (MODE == 0 || (MODE == 2 && blockIdx.y == 0)) detect2_body<T, false, NPOL, NBIT>(a, s_p, s_u, s_u0, s_w);
-    else detect2_body<T, true, NPOL, NBIT>(a, s_p, s_u, s_u0, s_w);
+    if (MODE == 0 || (MODE == 2 && blockIdx.y == 0)) detect2_body<T, false, NPOL, NBIT, DEPTH>(a, s_p, s_u, s_u0, s_w);
+    else detect2_body<T, true, NPOL, NBIT, DEPTH>(a, s_p, s_u, s_u0, s_w);
 }
 
-template <int T, int NPOL, int NBIT>
+template <int T, int NPOL, int NBIT, int DEPTH>
 static void launch_mode(const Detect2Args &a, int mode, dim3 grid, hipStream_t st)
 {
-    if (mode == 0) k_detect2<T, NPOL, NBIT, 0><<<grid, D2_THREADS, 0, st>>>(a);
-    else if (mode == 1) k_detect2<T, NPOL, NBIT, 1><<<grid, D2_THREADS, 0, st>>>(a);
-    else k_detect2<T, NPOL, NBIT, 2><<<grid, D2_THREADS, 0, st>>>(a);
+    if (mode == 0) k_detect2<T, NPOL, NBIT, 0, DEPTH><<<grid, D2_THREADS, 0, st>>>(a);
+    else if (mode == 1) k_detect2<T, NPOL, NBIT, 1, DEPTH><<<grid, D2_THREADS, 0, st>>>(a);
+    else k_detect2<T, NPOL, NBIT, 2, DEPTH><<<grid, D2_THREADS, 0, st>>>(a);
 }
 
-template <int T>
+template <int T, int DEPTH>
 static void launch_all(const Detect2Args &a, int mode, int npol, int nbit, dim3 grid, hipStream_t st)
 {
     if (npol == 1) {
-        if (nbit == 8) launch_mode<T, 1, 8>(a, mode, grid, st);
-        else if (nbit == 4) launch_mode<T, 1, 4>(a, mode, grid, st);
-        else launch_mode<T, 1, 2>(a, mode, grid, st);
+        if (nbit == 8) launch_mode<T, 1, 8, DEPTH>(a, mode, grid, st);
+        else if (nbit == 4) launch_mode<T, 1, 4, DEPTH>(a, mode, grid, st);
+        else launch_mode<T, 1, 2, DEPTH>(a, mode, grid, st);
     } else {
-        if (nbit == 8) launch_mode<T, 2, 8>(a, mode, grid, st);
-        else if (nbit == 4) launch_mode<T, 2, 4>(a, mode, grid, st);
-        else launch_mode<T, 2, 2>(a, mode, grid, st);
+        if (nbit == 8) launch_mode<T, 2, 8, DEPTH>(a, mode, grid, st);
+        else if (nbit == 4) launch_mode<T, 2, 4, DEPTH>(a, mode, grid, st);
+        else launch_mode<T, 2, 2, DEPTH>(a, mode, grid, st);
     }
 }
 
@@ -522,7 +539,16 @@ hipError_t launch_detect_pow(pb_handle *h, int nseg)
     a.oms = 1 - a.scale;
     a.tscale = (float)sqrt(1. / PB_NSCRUNCH);
     dim3 grid(PB_NCHANOUT / 32, h->cfg.rfi_mode == 2 ? 2 : 1, h->A);
-    if (h->R % 32 == 0) launch_all<32>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
-    else launch_all<8>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
+    // three chunks in flight where detect runs wholly beside the next batch's channeliser (it flags its own rows and
+    // starts straight behind the previous one), two otherwise (measured both ways, see the comment on DEPTH)
+    static const int depth_env = getenv("PB_DETECT_DEPTH") ? atoi(getenv("PB_DETECT_DEPTH")) : 0;   // 2 / 3: timing experiments
+    const bool deep = depth_env ? depth_env == 3
+                                : (D2_DEPTH_OVERLAPPED == 3 && pb_fused_kurtosis(h) && h->sets.size() >= 2 && h->A == 1);
+    if (h->R % 32 == 0) {
+        if (deep) launch_all<32, 3>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
+        else launch_all<32, 2>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
+    } else {
+        launch_all<8, 2>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
+    }
     return hipGetLastError();
 }
