@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void k_copy_out(uint4 *__restrict__ dst, const
 hipError_t launch_copy_out(uint8_t *host_pinned, const uint8_t *dev, size_t nbytes, hipStream_t st)
 {
     if (nbytes == 0) return hipSuccess;
-    if ((nbytes & 15) || ((uintptr_t)host_pinned & 15) || ((uintptr_t)dev & 15))
+    static const int use_dma = getenv("PB_COPY_DMA") ? atoi(getenv("PB_COPY_DMA")) : 0;    // timing experiments
+    if (use_dma || (nbytes & 15) || ((uintptr_t)host_pinned & 15) || ((uintptr_t)dev & 15))
         return hipMemcpyAsync(host_pinned, dev, nbytes, hipMemcpyDeviceToHost, st);
     void *dptr = nullptr;
     hipError_t e = hipHostGetDevicePointer(&dptr, host_pinned, 0);

@@ -220,8 +220,11 @@ static int create_impl(pb_handle *h)
             uint32_t mask[8];
             for (int i = 0; i < 8; ++i) mask[i] = (1u << det_cus) - 1u;
             HIPCHK(h, hipExtStreamCreateWithCUMask(&h->s_det, 8, mask));
-        } else
-        HIPCHK(h, hipStreamCreateWithPriority(&h->s_det, hipStreamNonBlocking, hi));
+        } else {
+            // (PB_DET_PRIO=0: detect's stream at the default priority; timing experiments)
+            static const int det_hi = getenv("PB_DET_PRIO") ? atoi(getenv("PB_DET_PRIO")) : 1;
+            HIPCHK(h, hipStreamCreateWithPriority(&h->s_det, hipStreamNonBlocking, det_hi ? hi : lo));
+        }
     }
     HIPCHK(h, hipStreamCreateWithFlags(&h->s_kur, hipStreamNonBlocking));
     HIPCHK(h, hipStreamCreateWithFlags(&h->s_copy, hipStreamNonBlocking));
