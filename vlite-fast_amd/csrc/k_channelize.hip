@@ -325,9 +325,24 @@ __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
 // the next batch's channeliser then starts straight behind this one and detect runs wholly beside it.
 // The input buffer is NOT patched for code 0 here (nobody reads it again but this workgroup): every staging fixes
 // the codes on the way (FIX).
+#ifdef KUR_STAMP
+// timing experiments (variant builds only, tools/kur_stamps.py): the clock at the phase boundaries of every workgroup
+__device__ unsigned long long g_kur_stamp[20480][8];
+extern "C" int pb_internal_kur_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kur_stamp), sizeof(g_kur_stamp));
+}
+#define KSTAMP(i) do { if (threadIdx.x == 0) kts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define KSTAMP(i)
+#endif
 __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
 {
     __shared__ __attribute__((aligned(16))) f2 buf[M_HALF];
+#ifdef KUR_STAMP
+    __shared__ unsigned long long kts[8];
+#endif
+    KSTAMP(0);
     int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -357,6 +372,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
         if (l1) sraw1[tid + 768] = fix_zero_codes(sb.t3);
     }
     __syncthreads();
+    KSTAMP(1);
     {
         // moments of the 50 blocks: exactly k_kurtosis_row's reduction (same leaves, same tree, same sharing of the
         // cross-lane levels between four blocks)
@@ -430,12 +446,14 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
         }
     }
     __syncthreads();
+    KSTAMP(2);
     if (tid < 50) {
         const float p = s2[tid] / PB_NKURTO;
         const float k = s4[tid] / PB_NKURTO / (p * p);
         sdag[tid] = dag_one(k, *a.dag);
     }
     __syncthreads();
+    KSTAMP(3);
     if (tid < 25) {
         const float dmax = fmaxf(sdag[tid], sdag[25 + tid]);
         const bool bad = dmax > 3.0f;  // DAG_THRESH
@@ -456,6 +474,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
     const unsigned mask = __builtin_amdgcn_readfirstlane(smw[0]);
     const float wrow = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(smw[1]));
     __syncthreads();        // mask and weight are in registers: the transforms may overwrite buf
+    KSTAMP(4);
 
     const bool all_bad = mask == 0x1ffffffu;
     const bool second = a.rfi_mode == 1 || (a.rfi_mode == 2 && mask != 0);
@@ -483,6 +502,17 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
         }
         channelize_pass<1, true>(a, buf, tid, seg, row, pol, ant, st, mask, wrow, prow, after_row, 1);
     }
+#ifdef KUR_STAMP
+    if (threadIdx.x == 0 && blockIdx.z == 0) {
+        const unsigned wg = blockIdx.x + gridDim.x * blockIdx.y;
+        if (wg < 20480) {
+            for (int i = 0; i < 5; ++i) g_kur_stamp[wg][i] = kts[i];
+            g_kur_stamp[wg][5] = __builtin_amdgcn_s_memtime();
+            g_kur_stamp[wg][6] = mask;
+            g_kur_stamp[wg][7] = __builtin_amdgcn_s_getreg(20 | (3 << 11));   // HW_REG_XCC_ID
+        }
+    }
+#endif
 }
 
 static bool check_consts(std::string &why)

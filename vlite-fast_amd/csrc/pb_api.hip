@@ -834,7 +834,10 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         hipStream_t s_main = h->stream;
         hipError_t e = hipSuccess;
         if (overlap) {
-            e = hipStreamWaitEvent(h->s_kur, h->ev_fftdone, 0);
+            // (PB_KUR_EARLY=1, three or more buffer sets: the kurtosis pass does not wait for the previous batch's
+            // channeliser -- it touches another set -- and runs beside it; timing experiments)
+            static const int kur_early = getenv("PB_KUR_EARLY") ? atoi(getenv("PB_KUR_EARLY")) : 0;
+            if (!(kur_early && h->sets.size() >= 3)) e = hipStreamWaitEvent(h->s_kur, h->ev_fftdone, 0);
             if (e == hipSuccess) e = hipStreamWaitEvent(h->s_kur, h->ev_chan, 0);  // flags / weights of this set free (its detect is done)
             h->stream = h->s_kur;
         } else if (h->sets.size() >= 2 && (h->staged || !fused)) {
