@@ -212,6 +212,13 @@ int pb_profile(pb_handle *h, int enable);
 int pb_get_timers(pb_handle *h, pb_timers *out, int reset);
 int pb_debug_fetch(pb_handle *h, int what, int ant, int seg, void *dst, size_t nbytes);
 
+/* Test hook for the flag decision (src/pb_kernels.cu:109-134, DAG_THRESH): the kernels decide "score > 3" from the
+ * cube root's ARGUMENT against crossings located at pb_create and evaluate the score itself only in the few-float
+ * bands around them.  For every binary32 kurtosis in [kur_lo, kur_hi] the device compares that decision with the
+ * score; *nmismatch must come back 0.  bands4 (may be NULL): t_lo_sure, t_lo_clear, t_hi_clear, t_hi_sure. */
+int pb_debug_dag_check(pb_handle *h, float kur_lo, float kur_hi, uint64_t *nchecked, uint64_t *nmismatch,
+                       float *bands4);
+
 /* channeliser alone, for the taps=4 parity test against polyphase_filterbank
  * (analysis/baseband.py:1207): x is nrows+taps-1 rows of 12500 float32 on the host,
  * out is nrows x 6251 complex64 (interleaved re,im). */

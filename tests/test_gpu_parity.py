@@ -383,3 +383,31 @@ def test_pipelined_sets_with_32_row_chunks_bit_exact(oracle, nsets, rfi_mode):
     if rfi_mode != 1:
         assert np.array_equal(np.concatenate(got["raw"]), np.concatenate([r.codes_raw for r in res]))
     assert np.array_equal(np.concatenate(got["kur"]), np.concatenate([r.codes_kur for r in res]))
+
+
+def test_flag_decision_without_the_cube_root_equals_the_score_for_every_float(oracle):
+    """The kernels decide "D'Agostino score > 3" from the cube root's argument against crossings located at
+    pb_create (the score itself only in the bands around them).  Exhaustive where it matters: every binary32
+    kurtosis in [1, 16] (all crossings of the N = 500 score lie there: 3 +- ~0.66) -- 33.5 million values -- plus
+    ranges far out on both sides, decision against score on the device: no mismatch.  And the crossings the
+    library found agree with the oracle's score to the float."""
+    lp = libpb()
+    with lp.PbHandle(rows_per_seg=8, max_seg=1) as h:
+        total = 0
+        for lo, hi in ((1.0, 16.0), (0.01, 0.0101), (50.0, 50.5), (1e6, 1.001e6), (1e-30, 1.001e-30)):
+            n, bad, bands = h.dag_check(lo, hi)
+            assert bad == 0, (lo, hi, bad)
+            total += n
+        assert total > 3.3e7
+    t_lo_sure, t_lo_clear, t_hi_clear, t_hi_sure = [np.float32(v) for v in bands]
+    assert 0 < t_lo_sure < t_lo_clear < t_hi_clear < t_hi_sure
+    # the bands are a few floats wide at most
+    assert int(t_lo_clear.view(np.uint32)) - int(t_lo_sure.view(np.uint32)) <= 8
+    assert int(t_hi_sure.view(np.uint32)) - int(t_hi_clear.view(np.uint32)) <= 8
+    # against the oracle: kurtosis values whose t lands just outside the bands
+    kur = np.linspace(1.5, 6.0, 200001).astype(np.float32)
+    dag = oracle.compute_dagostino(np.concatenate([kur, kur]))[:kur.size]
+    fl = dag > 3.0
+    # crossings in kurtosis: flagged below ~2.45 and above ~3.78, clear in between
+    i0, i1 = np.argmax(~fl), kur.size - np.argmax(~fl[::-1])
+    assert fl[:i0].all() and (~fl[i0:i1]).all() and fl[i1:].all() and 2.2 < kur[i0] < 2.7 and 3.5 < kur[i1 - 1] < 4.1

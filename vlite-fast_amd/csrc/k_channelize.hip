@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
     if (tid < 50) {
         const float p = s2[tid] / PB_NKURTO;
         const float k = s4[tid] / PB_NKURTO / (p * p);
-        sdag[tid] = dag_one(k, *a.dag);
+        sdag[tid] = dag_flag(k, *a.dag) ? 9.0f : 0.0f;     // (the flag only: no cube root, kurtosis_dev.h)
     }
     __syncthreads();
     KSTAMP(3);

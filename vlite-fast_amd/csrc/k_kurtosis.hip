@@ -174,7 +174,8 @@ __global__ __launch_bounds__(256, 6) void k_kurtosis_row(
         const int pol = tid / 25, blk = tid % 25;
         const float p = s2[tid] / PB_NKURTO;
         const float k = s4[tid] / PB_NKURTO / (p * p);
-        sdag[tid] = dag_one(k, dc);
+        // the score itself only where it is kept (statistics); a flag needs no cube root (dag_flag): 9 = "above"
+        sdag[tid] = (stats || (ROW_STATS && stats_fb)) ? dag_one(k, dc) : (dag_flag(k, dc) ? 9.0f : 0.0f);
         if (ROW_STATS && stats_fb) {
             spow[tid] = p;
             skur[tid] = k;
@@ -270,6 +271,37 @@ __global__ __launch_bounds__(256, 6) void k_kurtosis_row(
     }
     KU_STAMP(5);
     KU_STAMP_FLUSH();
+}
+
+// score > DAG_THRESH for n consecutive floats t from bit pattern bits0 on (pb_create: where the score crosses the
+// threshold, evaluated by the device that will evaluate the flags)
+__global__ void k_dag_scan(DagConsts c, uint32_t bits0, int n, uint8_t *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = dag_of_t(__uint_as_float(bits0 + (uint32_t)i), c) > 3.0f ? 1 : 0;
+}
+
+hipError_t launch_dag_scan(pb_handle *h, const DagConsts &c, uint32_t bits0, int n, uint8_t *d_out)
+{
+    k_dag_scan<<<(n + 255) / 256, 256, 0, h->stream>>>(c, bits0, n, d_out);
+    return hipGetLastError();
+}
+
+// the flag without the cube root (dag_flag) against the score itself for every float kurtosis in [bits_lo, bits_hi]
+__global__ void k_dag_check(DagConsts c, uint32_t bits_lo, uint64_t n, unsigned long long *__restrict__ mismatches)
+{
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float kur = __uint_as_float(bits_lo + (uint32_t)i);
+        bad += dag_flag(kur, c) != (dag_one(kur, c) > 3.0f);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+hipError_t launch_dag_check(pb_handle *h, uint32_t bits_lo, uint64_t n, unsigned long long *d_mismatches)
+{
+    k_dag_check<<<2048, 256, 0, h->stream>>>(h->dag, bits_lo, n, d_mismatches);
+    return hipGetLastError();
 }
 
 // plain unpack for rfi_mode 0 (convertarray only)

@@ -15,22 +15,22 @@ __device__ __forceinline__ float cvt_sample(unsigned u)
 
 // t^(float(1/3)) by Newton cube root in IEEE double: the same operation sequence as
 // orc_powf_third in the oracle, so that flags agree bit for bit (deviation 1).
-__device__ float dev_powf_third(float t)
+__host__ __device__ inline float dev_powf_third(float t)
 {
     double d = (double)t;
-    unsigned long long bits = (unsigned long long)__double_as_longlong(d);
+    unsigned long long bits = __builtin_bit_cast(unsigned long long, d);
     int e = (int)((bits >> 52) & 0x7ff) - 1023;
     int q = (e >= 0) ? e / 3 : -((-e + 2) / 3);
     int r = e - 3 * q;
     bits = (bits & 0x000fffffffffffffULL) | ((unsigned long long)(1023 + r) << 52);
-    double m = __longlong_as_double((long long)bits);
+    double m = __builtin_bit_cast(double, bits);
     double y = 1.0 + (m - 1.0) * (1.0 / 7.0);
 #pragma unroll 1
     for (int it = 0; it < 8; ++it) {
         double y2 = y * y;
         y = y - (y2 * y - m) / (3.0 * y2);
     }
-    double s = __longlong_as_double((long long)((unsigned long long)(1023 + q) << 52));
+    double s = __builtin_bit_cast(double, (unsigned long long)(1023 + q) << 52);
     double z = (y - 1.0) / (y + 1.0);
     double z2 = z * z;
     double lny = 2.0 * z * (1.0 + z2 * (1.0 / 3.0 + z2 * (1.0 / 5.0 + z2 * (1.0 / 7.0))));
@@ -39,14 +39,38 @@ __device__ float dev_powf_third(float t)
     return (float)(y * s * (1.0 + dexp * lnt));
 }
 
-__device__ float dag_one(float kur, const DagConsts &c)
+// the score as a function of t, the argument of the cube root (t > 0)
+__host__ __device__ inline float dag_of_t(float t, const DagConsts &c)
+{
+    const float v = (float)(c.Z1 * (c.Z2 - (double)dev_powf_third(t)));
+    return __builtin_fabsf(v);
+}
+__host__ __device__ inline float dag_t(float kur, const DagConsts &c)
+{
+    return (float)(c.one_m_2_over_A / (1. + ((double)kur - 3. - c.mu1) * c.Z3));
+}
+
+__device__ inline float dag_one(float kur, const DagConsts &c)
 {
     float dag = 9.0f;  // DAG_INF = DAG_THRESH + DAG_FB_THRESH + 1
     if (kur != 0.f) {  // true for NaN (all-zero block): t is NaN, t > 0 false, stays DAG_INF
-        float t = (float)(c.one_m_2_over_A / (1. + ((double)kur - 3. - c.mu1) * c.Z3));
-        if (t > 0) dag = fabsf((float)(c.Z1 * (c.Z2 - (double)dev_powf_third(t))));
+        const float t = dag_t(kur, c);
+        if (t > 0) dag = dag_of_t(t, c);
     }
     return dag;
+}
+
+// dag_one(kur) > DAG_THRESH without the cube root: t against the crossings found at pb_create (DagConsts), the
+// score itself only in the bands around them.  Same decision as the score, float for float (tests: every flag of
+// every parity test, and pb_debug_dag_check over every float kurtosis around both crossings).
+__device__ inline bool dag_flag(float kur, const DagConsts &c)
+{
+    if (!(kur != 0.f)) return true;            // kur == 0: the score stays DAG_INF
+    const float t = dag_t(kur, c);
+    if (!(t > 0)) return true;                 // NaN (all-zero block) or a negative argument: DAG_INF
+    if (t <= c.t_lo_sure || t >= c.t_hi_sure) return true;
+    if (t >= c.t_lo_clear && t <= c.t_hi_clear) return false;
+    return dag_of_t(t, c) > 3.0f;              // inside a band (rare)
 }
 
 __device__ __forceinline__ float4 cvt4(uint32_t w)

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "kurtosis_dev.h"
 #include "pb_internal.h"
 
 static std::string g_create_err;
@@ -88,12 +89,69 @@ static DagConsts make_dag(float NK)
     const double g1 = 6. * q / d2 * sqrt((6. * (NK + 3) * (NK + 5)) / d3);
     const double A = 6. + (8. / g1) * (2. / g1 + sqrt(1. + 4. / (g1 * g1)));
     DagConsts c;
+    c.t_lo_sure = c.t_hi_clear = 0.f;                                  // (no crossings known: every t is in a
+    c.t_lo_clear = c.t_hi_sure = __builtin_inff();                     //  "band", the score itself decides)
     c.one_m_2_over_A = (1 - 2. / A);
     c.mu1 = mu1;
     c.Z1 = sqrt(4.5 * A);
     c.Z2 = 1 - 2. / (9 * A);
     c.Z3 = sqrt(2. / (mu2 * (A - 4)));
     return c;
+}
+
+// Where the D'Agostino score crosses DAG_THRESH as a function of t (DagConsts): the crossings are located on the host
+// (the score is the same IEEE double arithmetic there) by bisection over the positive floats, then the DEVICE
+// evaluates the score on every float within DAG_WIN of each crossing and the bands are read off its answers: below /
+// above a crossing by more than the window the score is monotonic beyond doubt (one float step of t moves it by
+// 4e-7, the cube root's last-ulp wobble by at most 1.2e-6: three steps).
+#define DAG_WIN 256
+static int find_dag_bands(pb_handle *h, DagConsts &c)
+{
+    auto flagged = [&](uint32_t bits) { return dag_of_t(__builtin_bit_cast(float, bits), c) > 3.0f; };
+    const float t_mid = (float)(c.Z2 * c.Z2 * c.Z2);                 // score 0
+    const uint32_t b_mid = __builtin_bit_cast(uint32_t, t_mid);
+    uint32_t lo = __builtin_bit_cast(uint32_t, 1e-6f), hi = b_mid;   // flagged at lo, clear at hi
+    if (!flagged(lo) || flagged(hi)) return fail(h, PB_ESTATE, "D'Agostino score: no lower crossing");
+    while (hi - lo > 1) {
+        const uint32_t m = lo + (hi - lo) / 2;
+        if (flagged(m)) lo = m; else hi = m;
+    }
+    const uint32_t cross_lo = hi;
+    lo = b_mid;
+    hi = __builtin_bit_cast(uint32_t, 100.0f);                        // clear at lo, flagged at hi
+    if (flagged(lo) || !flagged(hi)) return fail(h, PB_ESTATE, "D'Agostino score: no upper crossing");
+    while (hi - lo > 1) {
+        const uint32_t m = lo + (hi - lo) / 2;
+        if (flagged(m)) hi = m; else lo = m;
+    }
+    const uint32_t cross_hi = hi;
+    const int n = 2 * DAG_WIN + 1;
+    uint8_t *d_f = nullptr;
+    std::vector<uint8_t> f(2 * n);
+    HIPCHK(h, hipMalloc((void **)&d_f, 2 * n));
+    hipError_t e = launch_dag_scan(h, c, cross_lo - DAG_WIN, n, d_f);
+    if (e == hipSuccess) e = launch_dag_scan(h, c, cross_hi - DAG_WIN, n, d_f + n);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(f.data(), d_f, 2 * n, hipMemcpyDeviceToHost);
+    (void)hipFree(d_f);
+    HIPCHK(h, e);
+    const uint8_t *a = f.data(), *b = f.data() + n;
+    // lower crossing: flagged ... flagged | band | clear ... clear
+    int first_clear = 0, last_flag = n - 1;
+    while (first_clear < n && a[first_clear]) ++first_clear;
+    while (last_flag >= 0 && !a[last_flag]) --last_flag;
+    // upper crossing: clear ... clear | band | flagged ... flagged
+    int first_flag = 0, last_clear = n - 1;
+    while (first_flag < n && !b[first_flag]) ++first_flag;
+    while (last_clear >= 0 && b[last_clear]) --last_clear;
+    if (first_clear < 8 || last_flag > n - 9 || last_flag < 0 || first_clear >= n || first_flag < 8 || last_clear > n - 9 ||
+        last_clear < 0 || first_flag >= n)
+        return fail(h, PB_ESTATE, "D'Agostino score: crossing not inside the scanned window");
+    c.t_lo_sure = __builtin_bit_cast(float, cross_lo - DAG_WIN + (uint32_t)(first_clear - 1));
+    c.t_lo_clear = __builtin_bit_cast(float, cross_lo - DAG_WIN + (uint32_t)(last_flag + 1));
+    c.t_hi_clear = __builtin_bit_cast(float, cross_hi - DAG_WIN + (uint32_t)(first_flag - 1));
+    c.t_hi_sure = __builtin_bit_cast(float, cross_hi - DAG_WIN + (uint32_t)(last_clear + 1));
+    return PB_OK;
 }
 
 template <class T>
@@ -321,6 +379,7 @@ static int create_impl(pb_handle *h)
     }
     h->dag = make_dag((float)PB_NKURTO);
     h->dag_fb = make_dag((float)PB_NFFT);
+    if (int rcb = find_dag_bands(h, h->dag)) return rcb;
     // (a copy in device memory for the channeliser that flags its own rows: ten fewer scalar registers of arguments)
     HIPCHK(h, hipMalloc((void **)&h->d_dag, sizeof(DagConsts)));
     HIPCHK(h, hipMemcpy(h->d_dag, &h->dag, sizeof(DagConsts), hipMemcpyHostToDevice));
@@ -1200,6 +1259,33 @@ extern "C" int pb_debug_fetch(pb_handle *h, int what, int ant, int seg, void *ds
         return PB_OK;
     }
     return fail(h, PB_EINVAL, "pb_debug_fetch: unknown item");
+}
+
+extern "C" int pb_debug_dag_check(pb_handle *h, float kur_lo, float kur_hi, uint64_t *nchecked, uint64_t *nmismatch,
+                                  float *bands4)
+{
+    if (!h || !nchecked || !nmismatch) return PB_EINVAL;
+    if (!(kur_lo > 0) || !(kur_hi >= kur_lo)) return fail(h, PB_EINVAL, "pb_debug_dag_check: 0 < kur_lo <= kur_hi");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const uint32_t b0 = __builtin_bit_cast(uint32_t, kur_lo), b1 = __builtin_bit_cast(uint32_t, kur_hi);
+    const uint64_t n = (uint64_t)(b1 - b0) + 1;
+    unsigned long long *d_bad = nullptr, bad = 0;
+    HIPCHK(h, hipMalloc((void **)&d_bad, sizeof bad));
+    hipError_t e = hipMemset(d_bad, 0, sizeof bad);
+    if (e == hipSuccess) e = launch_dag_check(h, b0, n, d_bad);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad);
+    HIPCHK(h, e);
+    *nchecked = n;
+    *nmismatch = bad;
+    if (bands4) {
+        bands4[0] = h->dag.t_lo_sure;
+        bands4[1] = h->dag.t_lo_clear;
+        bands4[2] = h->dag.t_hi_clear;
+        bands4[3] = h->dag.t_hi_sure;
+    }
+    return PB_OK;
 }
 
 extern "C" int pb_channelize_f32(pb_handle *h, const float *x, int nrows, int taps, float *out)

@@ -16,6 +16,12 @@ struct DagConsts {
     double one_m_2_over_A;  // (1 - 2./A)
     double mu1;
     double Z1, Z2, Z3;
+    // Where the score crosses DAG_THRESH, in terms of t = (1 - 2/A) / (1 + (kur - 3 - mu1) Z3) (the argument of the
+    // cube root): the block is flagged for 0 < t <= t_lo_sure and for t >= t_hi_sure, not flagged for
+    // t_lo_clear <= t <= t_hi_clear; in the (few floats wide, normally empty) bands between them the score itself is
+    // evaluated.  Found on the device at pb_create by evaluating the score on every float around the crossings
+    // (pb_api.hip: find_dag_bands), so that a flag never needs the cube root and its eight Newton steps.
+    float t_lo_sure, t_lo_clear, t_hi_clear, t_hi_sure;
 };
 
 struct FrbParams {
@@ -123,6 +129,8 @@ static inline uint32_t *pb_rowmask(pb_handle *h) { return (uint32_t *)(h->d_wrow
 // ---- launchers (each enqueues on h->stream and returns a hipError_t) ----
 hipError_t launch_kurtosis_flag(pb_handle *h, int nseg, bool write_f32);
 hipError_t launch_deframe(pb_handle *h, int ant, int seg0, size_t nframes_per_thread);
+hipError_t launch_dag_scan(pb_handle *h, const DagConsts &c, uint32_t bits0, int n, uint8_t *d_out);
+hipError_t launch_dag_check(pb_handle *h, uint32_t bits_lo, uint64_t n, unsigned long long *d_mismatches);
 hipError_t launch_inject_c64(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_detect(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_detect_pow(pb_handle *h, int nseg);

@@ -53,7 +53,7 @@ EXPORTS = ["pb_config_default", "pb_create", "pb_destroy", "pb_last_error", "pb_
            "pb_set_stream", "pb_sync", "pb_reset_bandpass", "pb_reset_history", "pb_get_bandpass", "pb_set_bandpass",
            "pb_submit_planar", "pb_submit_planar_dev", "pb_submit_vdif", "pb_submit_vdif_at", "pb_input_dev", "pb_process", "pb_set_frb_params", "pb_select_set", "pb_fetch", "pb_fetch_ptr",
            "pb_output_dev", "pb_coadd_local", "pb_set_coadd_target", "pb_coadd_release", "pb_set_coadd_stream", "pb_coadd_finish", "pb_coadd_fetch_ptr", "pb_profile", "pb_get_timers", "pb_host_alloc", "pb_host_free",
-           "pb_debug_fetch", "pb_channelize_f32", "pb_version", "pb_search_create", "pb_search_create_list", "pb_search_destroy",
+           "pb_debug_fetch", "pb_debug_dag_check", "pb_channelize_f32", "pb_version", "pb_search_create", "pb_search_create_list", "pb_search_destroy",
            "pb_search_last_error", "pb_search_info", "pb_search_run", "pb_search_set_baseline", "pb_search_peaks",
            "pb_search_timers"]
 
@@ -114,6 +114,7 @@ def load():
     L.pb_get_timers.argtypes = [vp, C.POINTER(PbTimers), C.c_int]
     L.pb_debug_fetch.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
     L.pb_channelize_f32.argtypes = [vp, fp, C.c_int, C.c_int, fp]
+    L.pb_debug_dag_check.argtypes = [vp, C.c_float, C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), fp]
     L.pb_version.restype = C.c_char_p
     L.pb_host_alloc.argtypes = [C.c_size_t]
     L.pb_host_alloc.restype = vp              # (a pointer: the default int restype would truncate it)
@@ -339,6 +340,14 @@ class PbHandle(object):
             a = np.empty(self.rows, np.float32)
         self._chk(self._L.pb_debug_fetch(self._h, what, ant, seg, a.ctypes.data_as(C.c_void_p), a.nbytes))
         return a
+
+    def dag_check(self, kur_lo, kur_hi):
+        """(floats checked, mismatches, bands): the flag decision without the cube root against the score itself for
+        every binary32 kurtosis in [kur_lo, kur_hi]"""
+        n, bad = C.c_uint64(), C.c_uint64()
+        bands = np.zeros(4, np.float32)
+        self._chk(self._L.pb_debug_dag_check(self._h, kur_lo, kur_hi, C.byref(n), C.byref(bad), _f32(bands)))
+        return n.value, bad.value, bands
 
     def channelize_f32(self, x, nrows, taps=1):
         x = np.ascontiguousarray(x, np.float32).ravel()
