@@ -353,11 +353,13 @@ def test_pipelined_buffer_sets_hipfft_backend(oracle):
         assert d.max() <= 1 and (d != 0).mean() < 2e-3
 
 
+@pytest.mark.parametrize("keep", [False, True])
 @pytest.mark.parametrize("nsets,rfi_mode", [(2, 2), (3, 2), (2, 1)])
-def test_pipelined_sets_with_32_row_chunks_bit_exact(oracle, nsets, rfi_mode):
+def test_pipelined_sets_with_32_row_chunks_bit_exact(oracle, nsets, rfi_mode, keep):
     """R = 64: detect's 32-row chunks, and -- pipelined, with the channeliser that flags its own rows -- its
     three-chunks-in-flight ring (launch_detect_pow picks DEPTH 3 there, 2 everywhere else); five batches through
-    reused buffer sets, collected nsets - 1 batches late, against the oracle's serial run."""
+    reused buffer sets, collected nsets - 1 batches late, against the oracle's serial run.  keep: the two-kernel path
+    (with three sets its kurtosis pass runs beside the previous batch's channeliser)."""
     lp = libpb()
     Rr, nseg, nb = 64, 2, 5
     data = make_input(37, Rr, nseg * nb)
@@ -369,7 +371,7 @@ def test_pipelined_sets_with_32_row_chunks_bit_exact(oracle, nsets, rfi_mode):
         for k in got:
             got[k].append(o[k])
 
-    with lp.PbHandle(nbit=8, rfi_mode=rfi_mode, rows_per_seg=Rr, max_seg=nseg, nsets=nsets) as h:
+    with lp.PbHandle(nbit=8, rfi_mode=rfi_mode, rows_per_seg=Rr, max_seg=nseg, nsets=nsets, debug_keep=keep) as h:
         for b in range(nb):
             h.select_set(b % nsets)
             for s in range(nseg):

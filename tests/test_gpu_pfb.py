@@ -245,11 +245,12 @@ def test_pfb_pipelined_two_sets_mode0_bit_exact(oracle):
     assert np.array_equal(np.concatenate(raw), ref)
 
 
-@pytest.mark.parametrize("nsets", [1, 2])
+@pytest.mark.parametrize("nsets", [1, 2, 3])
 def test_pfb_rfi_mode2_both_streams_bit_exact(oracle, nsets):
     """(b) RFI mode 2 as benchmarked: RFI bursts, a row with every block flagged (weight 0 for four output rows'
     window share), a strongly flagged stretch, a dropped frame, three batches (flags of the carried rows are used
-    by the next batch).  Raw AND excised codes bit-exact, weights bit-exact."""
+    by the next batch).  Raw AND excised codes bit-exact, weights bit-exact.  nsets = 3: the kurtosis pass of batch k + 1
+    runs beside the channeliser of batch k (it no longer waits for it), the PFB weights behind the history kernel."""
     lp = libpb()
     S, NB = 2, 3
     data = make_input(62, R, S * NB)

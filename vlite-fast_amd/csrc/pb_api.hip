@@ -893,9 +893,14 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         hipStream_t s_main = h->stream;
         hipError_t e = hipSuccess;
         if (overlap) {
-            // (PB_KUR_EARLY=1, three or more buffer sets: the kurtosis pass does not wait for the previous batch's
-            // channeliser -- it touches another set -- and runs beside it; timing experiments)
-            static const int kur_early = getenv("PB_KUR_EARLY") ? atoi(getenv("PB_KUR_EARLY")) : 0;
+            // Three or more buffer sets: the kurtosis pass of this batch touches nothing the previous batch's
+            // channeliser uses (another set; the PFB weights that follow it wait for the history kernel by ev_hist),
+            // so it does not wait for that channeliser and runs beside it -- taps = 4: 0.990 -> 0.965 ms per second
+            // of data, the two-kernel taps = 1 path 0.660 -> 0.623 (same box, alternating).  With two sets this
+            // set's flags and weights are still being read by the previous batch's channeliser's successor, detect,
+            // until ev_chan; the wait for the channeliser keeps the kurtosis pass beside that detect.
+            // PB_KUR_EARLY=0 restores the wait.
+            static const int kur_early = getenv("PB_KUR_EARLY") ? atoi(getenv("PB_KUR_EARLY")) : 1;
             if (!(kur_early && h->sets.size() >= 3)) e = hipStreamWaitEvent(h->s_kur, h->ev_fftdone, 0);
             if (e == hipSuccess) e = hipStreamWaitEvent(h->s_kur, h->ev_chan, 0);  // flags / weights of this set free (its detect is done)
             h->stream = h->s_kur;
@@ -908,13 +913,16 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         }
         h->staged = false;
         if (e == hipSuccess && !fused) {
-            StageTimer t(h, PB_ST_KURTOSIS);
-            e = launch_kurtosis_flag(h, nseg, hipfft);
+            {
+                StageTimer t(h, PB_ST_KURTOSIS);
+                e = launch_kurtosis_flag(h, nseg, hipfft);
+                t.stop();
+            }
             // taps = 4: the weights read the history the previous batch left (and the input staged after this
-            // point overwrites rows that the history kernel reads)
+            // point overwrites rows that the history kernel reads).  (Outside the stage timer: the wait may be long
+            // when the kurtosis pass ran early, the weights kernel itself takes 9 us.)
             if (e == hipSuccess && h->cfg.taps == 4) e = hipStreamWaitEvent(h->stream, h->ev_hist, 0);
             if (e == hipSuccess) e = launch_pfb_weights(h, nseg);
-            t.stop();
         }
         if (overlap) {
             if (e == hipSuccess) e = hipEventRecord(h->ev_kur, h->s_kur);
