@@ -25,15 +25,6 @@
 #endif
 #define PFB_ROW_LDS 12528    // 12500 bytes + up to 12 of alignment slack, padded to 16
 #define PFB_HIST_STRIDE 12512
-#ifndef PFB_STAGE_DMA
-#define PFB_STAGE_DMA 1      // rows go to LDS by global_load_lds_dwordx4 (0: through registers; timing experiments)
-#endif
-#ifndef PFB_COEF_PRE
-#define PFB_COEF_PRE 0      // blocks whose window coefficients are requested before the rows
-#endif
-#ifndef PFB_WIN_GROUP
-#define PFB_WIN_GROUP 5      // blocks of the window loop between scheduling barriers
-#endif
 
 struct PfbArgs {
     const uint8_t *in;       // [A][S][2][seg_samples]
@@ -74,27 +65,6 @@ __device__ __forceinline__ void pfb_pass(const PfbArgs &a, uint8_t *lds, int tid
                                          int ant, const unsigned (&mask)[4], unsigned differ, float w, size_t prow)
 {
     f2 *buf = (f2 *)lds;
-    // window coefficients of samples (2n, 2n+1), n = tid + 250 r, tap j: through a buffer descriptor
-    // with the lane part (8 tid) in the vector offset and (j, r) in the scalar offset
-    const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc((void *)a.fir, 0, 6250 * 4 * 8, 0x00020000);
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    // the four taps of sample pair n are 32 contiguous bytes, and consecutive lanes take consecutive
-    // n: two coalesced 16-byte loads per block r (taps 0,1 and 2,3) instead of four 8-byte ones
-    auto coef2 = [&](int jj, int r) __attribute__((always_inline)) {
-        if (PFB_DBG & 1) { f4 one = {1.f, 1.f, 1.f, 1.f}; return one; }
-        return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsF, tid * 32, (250 * r * 4 + jj) * 8, 0));
-    };
-#if PFB_COEF_PRE
-    // the first blocks' coefficients are requested before the rows: they arrive while the rows are on their way
-    f4 pre[2 * PFB_COEF_PRE];
-    if (tid < 250) {
-#pragma unroll
-        for (int r = 0; r < PFB_COEF_PRE; ++r) {
-            pre[2 * r] = coef2(0, r);
-            pre[2 * r + 1] = coef2(2, r);
-        }
-    }
-#endif
     // stage the four rows (16-byte loads of the aligned chunks that cover each row)
     unsigned off[4];
 #pragma unroll
@@ -122,38 +92,11 @@ __device__ __forceinline__ void pfb_pass(const PfbArgs &a, uint8_t *lds, int tid
         // code 0 ("no sample") is code 128 = 0.0: the kurtosis kernel has patched the input buffer; history rows
         // (zero-filled before the stream starts) and RFI mode 0 (no kurtosis pass) are patched here, four bytes
         // per instruction (fft_lds.h)
-        if (a.rfi_mode == 0 || rr < 0) {
-            // (all four requests first: a loop over a run-time count is not unrolled, and each of its loads would
-            // wait for the one before)
-            const uint4 q0 = src16[tid], q1 = src16[tid + 256], q2 = src16[tid + 512];
-            uint4 q3 = make_uint4(0u, 0u, 0u, 0u);
-            const bool last = tid + 768 < nch;
-            if (last) q3 = src16[tid + 768];
-            dst[tid] = fix_zero_codes(q0);
-            dst[tid + 256] = fix_zero_codes(q1);
-            dst[tid + 512] = fix_zero_codes(q2);
-            if (last) dst[tid + 768] = fix_zero_codes(q3);
-        } else {
-#if PFB_STAGE_DMA
-            // straight into LDS (global_load_lds_dwordx4): no registers, no ds_write; a wave's 64 lanes fill 1 KB
-            // from the wave-uniform LDS address up
-            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int i = t * 256 + tid;
-                if (t < 3 || i < nch)              // a row is 782 or 783 chunks
-                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src16 + i),
-                                                     (void __attribute__((address_space(3))) *)(dst + t * 256 + wv * 64),
-                                                     16, 0, 0);
-            }
-#else
+        if (a.rfi_mode == 0 || rr < 0)
+            for (int i = tid; i < nch; i += 256) dst[i] = fix_zero_codes(src16[i]);
+        else
             for (int i = tid; i < nch; i += 256) dst[i] = src16[i];
-#endif
-        }
     }
-#if PFB_STAGE_DMA
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     __syncthreads();
 
     f2 v[25];
@@ -163,6 +106,17 @@ __device__ __forceinline__ void pfb_pass(const PfbArgs &a, uint8_t *lds, int tid
         const uint16_t *s1 = (const uint16_t *)(lds + 1 * PFB_ROW_LDS + off[1]);
         const uint16_t *s2 = (const uint16_t *)(lds + 2 * PFB_ROW_LDS + off[2]);
         const uint16_t *s3 = (const uint16_t *)(lds + 3 * PFB_ROW_LDS + off[3]);
+        // window coefficients of samples (2n, 2n+1), n = tid + 250 r, tap j: through a buffer descriptor
+        // with the lane part (8 tid) in the vector offset and (j, r) in the scalar offset
+        const __amdgpu_buffer_rsrc_t rsF =
+            __builtin_amdgcn_make_buffer_rsrc((void *)a.fir, 0, 6250 * 4 * 8, 0x00020000);
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        // the four taps of sample pair n are 32 contiguous bytes, and consecutive lanes take consecutive
+        // n: two coalesced 16-byte loads per block r (taps 0,1 and 2,3) instead of four 8-byte ones
+        auto coef2 = [&](int jj, int r) __attribute__((always_inline)) {
+            if (PFB_DBG & 1) { f4 one = {1.f, 1.f, 1.f, 1.f}; return one; }
+            return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsF, tid * 32, (250 * r * 4 + jj) * 8, 0));
+        };
         const unsigned m0 = kur ? mask[0] : 0u, m1 = kur ? mask[1] : 0u, m2 = kur ? mask[2] : 0u,
                        m3 = kur ? mask[3] : 0u;
 #pragma unroll
@@ -179,19 +133,14 @@ __device__ __forceinline__ void pfb_pass(const PfbArgs &a, uint8_t *lds, int tid
             const unsigned w1 = (PFB_DBG & 2) ? w0 : pick(m1, s1[n]), w2 = (PFB_DBG & 2) ? w0 : pick(m2, s2[n]), w3 = (PFB_DBG & 2) ? w0 : pick(m3, s3[n]);
             // sum_j taps[j] * x_j, products then left-to-right adds (the order of k_channelize_f32),
             // re and im side by side in packed instructions
-#if PFB_COEF_PRE
-            const f4 c01 = r < PFB_COEF_PRE ? pre[2 * (r < PFB_COEF_PRE ? r : 0)] : coef2(0, r);
-            const f4 c23 = r < PFB_COEF_PRE ? pre[2 * (r < PFB_COEF_PRE ? r : 0) + 1] : coef2(2, r);
-#else
             const f4 c01 = coef2(0, r), c23 = coef2(2, r);
-#endif
             f2 acc = mk2(c01.x, c01.y) * cvt_pair_c(w0);
             acc = acc + mk2(c01.z, c01.w) * cvt_pair_c(w1);
             acc = acc + mk2(c23.x, c23.y) * cvt_pair_c(w2);
             acc = acc + mk2(c23.z, c23.w) * cvt_pair_c(w3);
             v[r] = acc;
             // five blocks at a time: letting the scheduler hoist all 100 coefficient loads spills
-            if (r % PFB_WIN_GROUP == PFB_WIN_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+            if (r % 5 == 4) __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();
@@ -293,6 +242,68 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
 }
 
 
+// Three consecutive output rows of one (segment, pol) per 768-thread workgroup: each group of four waves runs the
+// pass above on its own third of LDS, all twelve waves meet at the same barriers.  Occupancy is what three separate
+// workgroups have (12 waves, 150 KB per CU); what changes is WHEN the three transforms of a CU ask for the window's
+// 200 KB and for their input rows (6 distinct rows instead of 12): within a few hundred cycles of one another, so
+// that two of every three requests find the line in the CU's L1 (or already on its way there) instead of going to L2.
+#define PFB3_IDLE_BARRIERS 6            // barriers of one pfb_pass: staging, window, four in fft6250
+__device__ __forceinline__ void pfb_idle()
+{
+#pragma unroll
+    for (int i = 0; i < PFB3_IDLE_BARRIERS; ++i) __syncthreads();
+}
+
+__global__ __launch_bounds__(768, 1) void k_channelize_pfb3(PfbArgs a, int ntriple, int per_xcd)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds3[3 * 4 * PFB_ROW_LDS];
+    const int g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    int tid = threadIdx.x & 255;
+    // every XCD a contiguous eighth of the segment's row triples (see k_channelize_pfb)
+    const int tb = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || tb >= ntriple) return;
+    const int row = tb * 3 + g;
+    const bool present_row = row < a.R;
+    const int seg = blockIdx.y >> 1, pol = blockIdx.y & 1, ant = blockIdx.z;
+    const int grow = seg * a.R + row;
+    uint8_t *lds = lds3 + g * (4 * PFB_ROW_LDS);
+
+    unsigned mask[4] = {0, 0, 0, 0};
+    unsigned differ = 0;
+    float w = 1.f;
+    if (a.rfi_mode && present_row) {
+        w = a.wrow[(size_t)ant * a.wrow_ant_stride + grow];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rr = grow - 3 + j;
+            const bool present = rr >= 0 || a.hvalid[ant * 3 + (3 + rr)] != 0;
+            mask[j] = present ? row_mask(a, ant, rr) : 0u;
+            differ |= mask[j];
+        }
+    }
+    const size_t prow = (size_t)ant * a.p_ant_stride + (((size_t)seg * 2 + pol) * a.R + row) * PB_NCHANOUT;
+    if (a.rfi_mode != 1) {
+        if (present_row) pfb_pass<0>(a, lds, tid, grow, seg, row, pol, ant, mask, differ, w, prow);
+        else pfb_idle();
+    }
+    if (a.rfi_mode == 0) return;
+    const bool need = present_row && (a.rfi_mode == 1 || differ != 0);
+    // (a barrier as well: the raw passes have finished reading their FFT buffers)
+    if (!__syncthreads_or(need ? 1 : 0)) return;
+    if (need && w == 0.f) {
+        for (int c = tid; c < PB_NCHANOUT; c += 256) a.Pkur[prow + c] = __builtin_inff();
+        pfb_idle();
+        return;
+    }
+    if (!need) {
+        pfb_idle();
+        return;
+    }
+    asm volatile("" : "+v"(tid));
+    pfb_pass<1>(a, lds, tid, grow, seg, row, pol, ant, mask, differ, w, prow);
+}
+
+
 // row weights of the PFB mode (see the header comment); overwrites wrow[g]
 __global__ void k_pfb_weights(const uint32_t *__restrict__ rowmask, size_t wrow_ant_stride,
                               const uint8_t *__restrict__ hflags, const float *__restrict__ tapE,
@@ -388,6 +399,13 @@ hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now)
     a.R = h->R;
     a.rfi_mode = h->cfg.rfi_mode;
     a.inject_now = inject_now;
+    static const int rows3 = getenv("PB_PFB_ROWS3") ? atoi(getenv("PB_PFB_ROWS3")) : 0;
+    if (rows3) {
+        const int ntriple = (h->R + 2) / 3, per_xcd = (ntriple + 7) / 8;
+        dim3 grid3((unsigned)(8 * per_xcd), (unsigned)(nseg * 2), (unsigned)h->A);
+        k_channelize_pfb3<<<grid3, 768, 0, h->stream>>>(a, ntriple, per_xcd);
+        return hipGetLastError();
+    }
     dim3 grid((unsigned)h->R, (unsigned)(nseg * 2), (unsigned)h->A);
     k_channelize_pfb<<<grid, 256, 0, h->stream>>>(a);
     return hipGetLastError();

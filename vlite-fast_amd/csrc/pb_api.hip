@@ -350,13 +350,15 @@ static int create_impl(pb_handle *h)
     int rc = build_fft_tables(h);
     if (rc) return rc;
     if (c.taps == 4) {
-        const size_t hb = A * 2 * 3 * 12512;
+        // two slots each: a batch's channeliser and weights read slot hist_rd, its history kernel fills the other one
+        const size_t hb = 2 * A * 2 * 3 * 12512;
         HIPCHK(h, dmalloc(h, &h->d_hist_in, hb));
         HIPCHK(h, hipMemset(h->d_hist_in, 0, hb));
-        HIPCHK(h, dmalloc(h, &h->d_hist_flags, A * 3 * PB_BLK_PER_FFT));
-        HIPCHK(h, hipMemset(h->d_hist_flags, 1, A * 3 * PB_BLK_PER_FFT));
-        HIPCHK(h, dmalloc(h, &h->d_hist_valid, A * 3));
-        HIPCHK(h, hipMemset(h->d_hist_valid, 0, A * 3));
+        HIPCHK(h, dmalloc(h, &h->d_hist_flags, 2 * A * 3 * PB_BLK_PER_FFT));
+        HIPCHK(h, hipMemset(h->d_hist_flags, 1, 2 * A * 3 * PB_BLK_PER_FFT));
+        HIPCHK(h, dmalloc(h, &h->d_hist_valid, 2 * A * 3));
+        HIPCHK(h, hipMemset(h->d_hist_valid, 0, 2 * A * 3));
+        h->hist_rd = 0;
         // window energy per (tap, 500-sample block), from the float taps the kernel multiplies by
         std::vector<float> taps((size_t)4 * PB_NFFT), E(101);
         HIPCHK(h, hipMemcpy(taps.data(), h->ft.taps, taps.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -426,6 +428,7 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
     h->d_wrow = h->d_stats = h->d_fraw = h->d_fkur = h->d_Praw = h->d_Pkur = h->d_bp = h->d_ave = nullptr;
     h->d_frb_delays = nullptr;
     h->d_hist_in = h->d_hist_flags = h->d_hist_valid = nullptr;
+    h->hist_rd = 0;
     h->d_tapE = nullptr;
     h->d_dag = nullptr;
     h->frb_width = 0.f;
@@ -564,12 +567,10 @@ static hipError_t submit_stream(pb_handle *h, hipStream_t *out)
     *out = h->s_kur;
     h->staged = true;          // the next pb_process orders its first kernel behind s_kur
     if (h->last_set == h->cur_set) {
-        // refilling the set that was processed last: behind that whole batch -- detect / copy-out (ev_alldone)
-        // and, with taps = 4, the history kernel, which reads the last three rows of d_in on the main stream
-        // AFTER ev_fftdone and is therefore not covered by ev_alldone
-        hipError_t e = hipStreamWaitEvent(h->s_kur, h->ev_alldone, 0);
-        if (e == hipSuccess && h->cfg.taps == 4) e = hipStreamWaitEvent(h->s_kur, h->ev_hist, 0);
-        return e;
+        // refilling the set that was processed last: behind that whole batch -- detect / copy-out (ev_alldone); with
+        // taps = 4 the history kernel, which reads the last three rows of d_in, ran on this very stream or before
+        // the channeliser that detect followed
+        return hipStreamWaitEvent(h->s_kur, h->ev_alldone, 0);
     }
     // hipFFT back end: its kurtosis pass (the last reader of d_in) runs on the MAIN stream, which s_kur is
     // not ordered behind: staging batch k+2 into this set must wait for the latest FFT stage, which is
@@ -609,9 +610,12 @@ extern "C" int pb_reset_history(pb_handle *h, int ant)
     if (h->cfg.taps != 4) return PB_OK;           // only the PFB window carries rows across calls
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, sync_all(h));
-    HIPCHK(h, hipMemset(h->d_hist_in + (size_t)ant * 2 * 3 * 12512, 0, (size_t)2 * 3 * 12512));
-    HIPCHK(h, hipMemset(h->d_hist_flags + (size_t)ant * 3 * PB_BLK_PER_FFT, 1, 3 * PB_BLK_PER_FFT));
-    HIPCHK(h, hipMemset(h->d_hist_valid + (size_t)ant * 3, 0, 3));
+    for (int slot = 0; slot < 2; ++slot) {
+        const size_t a = (size_t)slot * h->A + ant;
+        HIPCHK(h, hipMemset(h->d_hist_in + a * 2 * 3 * 12512, 0, (size_t)2 * 3 * 12512));
+        HIPCHK(h, hipMemset(h->d_hist_flags + a * 3 * PB_BLK_PER_FFT, 1, 3 * PB_BLK_PER_FFT));
+        HIPCHK(h, hipMemset(h->d_hist_valid + a * 3, 0, 3));
+    }
     return PB_OK;
 }
 
@@ -894,7 +898,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         hipError_t e = hipSuccess;
         if (overlap) {
             // Three or more buffer sets: the kurtosis pass of this batch touches nothing the previous batch's
-            // channeliser uses (another set; the PFB weights that follow it wait for the history kernel by ev_hist),
+            // channeliser uses (another set; the PFB history kernel behind it waits for that channeliser itself),
             // so it does not wait for that channeliser and runs beside it -- taps = 4: 0.990 -> 0.965 ms per second
             // of data, the two-kernel taps = 1 path 0.660 -> 0.623 (same box, alternating).  With two sets this
             // set's flags and weights are still being read by the previous batch's channeliser's successor, detect,
@@ -918,14 +922,23 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
                 e = launch_kurtosis_flag(h, nseg, hipfft);
                 t.stop();
             }
-            // taps = 4: the weights read the history the previous batch left (and the input staged after this
-            // point overwrites rows that the history kernel reads).  (Outside the stage timer: the wait may be long
-            // when the kurtosis pass ran early, the weights kernel itself takes 9 us.)
-            if (e == hipSuccess && h->cfg.taps == 4) e = hipStreamWaitEvent(h->stream, h->ev_hist, 0);
+            // taps = 4: the weights read the flags of the previous batch's last rows (history slot hist_rd, filled by
+            // that batch's history kernel earlier on this stream).
             if (e == hipSuccess) e = launch_pfb_weights(h, nseg);
+            if (e == hipSuccess && h->cfg.taps == 4) {
+                // The channeliser only needs what has been queued up to here: release it now.  Then keep this
+                // batch's last three rows and flags for the next one in the OTHER history slot -- the one the
+                // previous batch's channeliser reads, hence behind it (ev_fftdone still holds its record); the next
+                // batch's weights and staging follow on this stream, its channeliser behind them.  (Round 2 ran the
+                // history kernel behind the channeliser on the main stream and the next weights behind THAT: two
+                // cross-stream hand-overs between consecutive channelisers.)
+                if (overlap) e = hipEventRecord(h->ev_kur, h->s_kur);
+                if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->ev_fftdone, 0);
+                if (e == hipSuccess) e = launch_pfb_history(h, nseg);
+            }
         }
         if (overlap) {
-            if (e == hipSuccess) e = hipEventRecord(h->ev_kur, h->s_kur);
+            if (e == hipSuccess && h->cfg.taps != 4) e = hipEventRecord(h->ev_kur, h->s_kur);
             h->stream = s_main;
             if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->ev_kur, 0);
         }
@@ -947,10 +960,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         t.stop();
     }
     HIPCHK(h, hipEventRecord(h->ev_fftdone, h->stream));
-    if (h->cfg.taps == 4 && !hipfft) {
-        HIPCHK(h, launch_pfb_history(h, nseg));
-        HIPCHK(h, hipEventRecord(h->ev_hist, h->stream));
-    }
+    if (h->cfg.taps == 4) h->hist_rd ^= 1;       // the next batch reads what this batch's history kernel has kept
     h->last_set = h->cur_set;
     // With two or more buffer sets, detect + D2H of this batch run on the second stream so that they
     // overlap the NEXT batch's kurtosis and channeliser.  Detect is latency-bound on its serial

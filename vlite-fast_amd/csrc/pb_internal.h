@@ -73,9 +73,10 @@ struct pb_handle {
     float *d_ave;          // [A][2 streams][S][ave_per_seg]
     float *d_coadd_target; // nant = 1: the coadd stream's plane of antenna 0 goes here instead (pb_set_coadd_target)
     float *d_frb_delays;   // [6251]
-    uint8_t *d_hist_in;    // taps=4: [A][2][3][12512] last three rows of the previous batch
-    uint8_t *d_hist_flags; // taps=4: [A][3][25] their kurtosis flags (1 = flagged / no data)
-    uint8_t *d_hist_valid; // taps=4: [A][3] slot holds data
+    uint8_t *d_hist_in;    // taps=4: [2 slots][A][2][3][12512] last three rows of the previous batch
+    int hist_rd;           // the slot the current batch reads (its history kernel fills the other)
+    uint8_t *d_hist_flags; // taps=4: [2][A][3][25] their kurtosis flags (1 = flagged / no data)
+    uint8_t *d_hist_valid; // taps=4: [2][A][3] slot holds data
     float *d_tapE;         // taps=4: [4][25] window energy per (tap, block) + total at [100]
     float frb_width, frb_amp;   // inject_frb parameters (rows, amplitude factor)
     // --- pipeline slots: the d_* buffers above (except d_bp, d_vdif, tables) exist once per
@@ -139,7 +140,7 @@ hipError_t launch_copy_out(uint8_t *host_pinned, const uint8_t *dev, size_t nbyt
 hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_pfb_weights(pb_handle *h, int nseg);
-hipError_t launch_pfb_history(pb_handle *h, int nseg);   // taps = 4: after the channeliser (off the path to detect)   // taps = 4: after the kurtosis pass, before the channeliser
+hipError_t launch_pfb_history(pb_handle *h, int nseg);   // taps = 4: behind the weights, into the history slot the batch does not read
 hipError_t launch_channelize_f32(pb_handle *h, const float *d_x, int nrows, int taps, float2 *d_out);
 hipError_t launch_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate, hipStream_t st);
 hipError_t launch_coadd_digitise(pb_handle *h, int nseg, const float *d_sum, float scale,
