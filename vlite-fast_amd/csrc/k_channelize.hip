@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
 // the codes on the way (FIX).
 #ifdef KUR_STAMP
 // timing experiments (variant builds only, tools/kur_stamps.py): the clock at the phase boundaries of every workgroup
-__device__ unsigned long long g_kur_stamp[20480][8];
+__device__ unsigned long long g_kur_stamp[4][10240][10];   // the last four launches (a.frb.since counts them); [8], [9]: s_memrealtime (100 MHz, one clock for the chip) at entry / exit
 extern "C" int pb_internal_kur_stamps(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kur_stamp), sizeof(g_kur_stamp));
@@ -343,6 +343,9 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
     __shared__ unsigned long long kts[8];
 #endif
     KSTAMP(0);
+#ifdef KUR_STAMP
+    if (threadIdx.x == 0) kts[6] = __builtin_amdgcn_s_memrealtime();
+#endif
     int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -505,11 +508,15 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
 #ifdef KUR_STAMP
     if (threadIdx.x == 0 && blockIdx.z == 0) {
         const unsigned wg = blockIdx.x + gridDim.x * blockIdx.y;
-        if (wg < 20480) {
-            for (int i = 0; i < 5; ++i) g_kur_stamp[wg][i] = kts[i];
-            g_kur_stamp[wg][5] = __builtin_amdgcn_s_memtime();
-            g_kur_stamp[wg][6] = mask;
-            g_kur_stamp[wg][7] = __builtin_amdgcn_s_getreg(20 | (3 << 11));   // HW_REG_XCC_ID
+        if (wg < 10240) {
+            unsigned long long(*g)[10] = g_kur_stamp[a.frb.since & 3];
+            for (int i = 0; i < 5; ++i) g[wg][i] = kts[i];
+            g[wg][5] = __builtin_amdgcn_s_memtime();
+            g[wg][6] = mask;
+            g[wg][7] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (3 << 11)) |       // HW_REG_XCC_ID
+                       ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) << 8);  // HW_REG_HW_ID
+            g[wg][8] = kts[6];
+            g[wg][9] = __builtin_amdgcn_s_memrealtime();
         }
     }
 #endif
@@ -561,7 +568,12 @@ hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now)
     a.frb.delays = (inject_now > 0) ? h->d_frb_delays : nullptr;
     a.frb.width = h->frb_width;
     a.frb.amp = h->frb_amp;
+#ifdef KUR_STAMP
+    static int kur_launches = 0;
+    a.frb.since = kur_launches++;     // (unused by the kernels: which of the four stamp buffers)
+#else
     a.frb.since = 0;
+#endif
     a.R = h->R;
     a.rfi_mode = h->cfg.rfi_mode;
     a.inject_now = inject_now;

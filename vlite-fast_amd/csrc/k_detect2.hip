@@ -56,6 +56,9 @@ struct Detect2Args {
 #ifndef D2_LOAD_AUX
 #define D2_LOAD_AUX 0              // cache-policy bits of the plane loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
 #endif
+#ifndef D2_PRIO_A
+#define D2_PRIO_A 3                // wave priority of the recurrence wave
+#endif
 #ifndef D2_PRIO_B
 #define D2_PRIO_B 0                // wave priority of the loader and phase-B waves (the recurrence wave runs at 3)
 #endif
@@ -84,6 +87,14 @@ __device__ unsigned long long g_d2_stamp[8][4];
 extern "C" int pb_internal_d2_stamps(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_d2_stamp), sizeof(g_d2_stamp));
+}
+// start / end (s_memrealtime, 100 MHz), XCC_ID | HW_ID << 8 and launch number of every workgroup of the last 64
+// launches: [launch % 64][wg][4]
+__device__ unsigned long long g_d2_wg[64][256][4];
+__device__ unsigned g_d2_wgcnt[256];
+extern "C" int pb_internal_d2_wg(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_d2_wg), sizeof(g_d2_wg));
 }
 #define D2_NOW() ((long long)__builtin_amdgcn_s_memtime())
 #else
@@ -290,6 +301,7 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
     const int bi = b_index(wave);
 #ifdef D2_STAMP
     StepClock clk;
+    const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
     if (wave == D2_WAVE_L) {
@@ -334,7 +346,7 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
         }
     } else if (wave == D2_WAVE_A) {
         // ---- A: the recurrence.  lane -> (pol, channel)
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(D2_PRIO_A);
         const int polA = lane >> 5, cA = cg * 32 + (lane & 31);
         const float *inA = Pant + (size_t)polA * pol_stride + cA;
         float *bpp = a.bp + (((size_t)ant * 2 + stream) * 2 + polA) * PB_NCHANOUT + cA;
@@ -474,9 +486,22 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
     }
 #ifdef D2_STAMP
     if (blockIdx.x == 17 && blockIdx.y == 1 && blockIdx.z == 0 && lane == 0) {
-        g_d2_stamp[wave & 7][0] = (unsigned long long)clk.work;
-        g_d2_stamp[wave & 7][1] = (unsigned long long)clk.wait;
-        g_d2_stamp[wave & 7][2] = (unsigned long long)clk.extra;
+        // accumulated over launches (launches of one stream follow one another): the reader takes differences
+        g_d2_stamp[wave & 7][0] += (unsigned long long)clk.work;
+        g_d2_stamp[wave & 7][1] += (unsigned long long)clk.wait;
+        g_d2_stamp[wave & 7][2] += (unsigned long long)clk.extra;
+        g_d2_stamp[wave & 7][3] += 1ull;
+    }
+    if (wave == 0 && lane == 0 && blockIdx.z == 0) {
+        const unsigned wg = blockIdx.x + gridDim.x * blockIdx.y;
+        if (wg < 256) {
+            const unsigned n = g_d2_wgcnt[wg]++;
+            g_d2_wg[n & 63][wg][0] = wg_t0;
+            g_d2_wg[n & 63][wg][1] = __builtin_amdgcn_s_memrealtime();
+            g_d2_wg[n & 63][wg][2] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (3 << 11)) |
+                                     ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) << 8);   // XCC_ID, HW_ID
+            g_d2_wg[n & 63][wg][3] = n;
+        }
     }
 #endif
 }
