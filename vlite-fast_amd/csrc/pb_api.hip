@@ -616,6 +616,7 @@ extern "C" int pb_reset_history(pb_handle *h, int ant)
         HIPCHK(h, hipMemset(h->d_hist_flags + a * 3 * PB_BLK_PER_FFT, 1, 3 * PB_BLK_PER_FFT));
         HIPCHK(h, hipMemset(h->d_hist_valid + a * 3, 0, 3));
     }
+    HIPCHK(h, hipStreamSynchronize(nullptr));     // (the handle's streams do not wait for the null stream by themselves)
     return PB_OK;
 }
 
