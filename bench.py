@@ -233,16 +233,16 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
                     h.submit_planar_dev(a, s, sec[s][0].data_ptr(), sec[s][1].data_ptr(), n)
             h.sync()
         del sec
-    d_sum = torch.zeros(S * h.ave_per_seg, dtype=torch.float32, device=dev) if coadd else None
-    d_sums = None
-    if coadd and A == 1 and args.backend == "lds":
-        # one antenna per GPU: detect writes the plane to be reduced straight into a buffer of ours, one per
-        # buffer set, and the local sum needs no kernel (pb_set_coadd_target)
-        d_sums = [torch.zeros(S * h.ave_per_seg, dtype=torch.float32, device=dev) for _ in range(NSETS)]
-        for st in range(NSETS):
-            h.select_set(st)
-            h.set_coadd_target(d_sums[st].data_ptr())
     nant_total = world * A
+    leg = None
+    if coadd:
+        # The incoherent sum (coadd.IncoherentCoadd, the class the coadder host runs) has a stream of its own: local
+        # sum -> RCCL reduce -> requantise of batch k are ordered on it by the device and run beside the kernels of
+        # batch k+1; no host synchronisation inside a step.  One antenna per GPU: detect writes the plane to be
+        # reduced straight into the leg's buffer of the batch's set and the local sum needs no kernel.
+        cmod = importlib.import_module("vlite-fast_amd.coadd")
+        leg = cmod.IncoherentCoadd(h, nant_total, dev, root=0, backend=args.dist_backend,
+                                   parts=int(os.environ.get("PB_COADD_PARTS", "7")))     # (parts: timing experiments)
     nstream_out = (0, 1) if args.rfi_mode == 2 else ((0,) if args.rfi_mode == 0 else (1,))
     state = {"k": 0, "sink": 0, "coadds": 0}
 
@@ -255,43 +255,16 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
                 v = h.fetch_view(a, st, S)
                 state["sink"] += int(v[0]) + int(v[-1])
 
-    ts = None
-    if coadd:
-        # The incoherent sum has a stream of its own: local sum -> RCCL reduce -> requantise of batch k
-        # are ordered on it by the device (the library makes it wait for detect of batch k with an
-        # event) and run beside the kernels of batch k+1; no host synchronisation inside a step.
-        ts = torch.cuda.Stream(device=dev)
-        h.sync()
-        h.set_coadd_stream(ts.cuda_stream)
-
-    parts = int(os.environ.get("PB_COADD_PARTS", "7"))     # timing experiments: 1 local sum, 2 reduce, 4 finish
-
     def finish_batch(j):
         """Batch j is done on the device once its filterbank bytes are here (collect waits for them), so its
         incoherent-sum leg -- local sum (nothing to launch with a coadd target), RCCL reduce, requantisation on
         the root -- is queued on the coadd stream without a device-side wait for detect, one step behind the
         batch itself, and runs beside the kernels of the batches after it."""
         collect(j)                                    # (selects buffer set j mod NSETS)
-        if coadd and parts:
-            ds = d_sums[j % NSETS] if d_sums is not None else d_sum
-            with torch.cuda.stream(ts):
-                if parts & 1:
-                    h.coadd_local(S, ds.data_ptr())
-                if not parts & 2:
-                    pass
-                elif args.dist_backend == "nccl":
-                    dist.reduce(ds, dst=0, op=dist.ReduceOp.SUM)
-                else:                     # gloo rehearsal: through host memory
-                    ts.synchronize()
-                    t = ds.cpu()
-                    dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
-                    ds.copy_(t)
-                if rank == 0 and parts & 4:
-                    h.coadd_finish(S, ds.data_ptr(), nant_total, blocking=False)
-                if d_sums is not None:
-                    h.coadd_release()
-            if rank == 0 and parts & 4 and state["coadds"]:
-                v = h.coadd_view(S, age=1)            # coadded bytes of the batch before
+        if leg is not None and leg.parts:
+            leg.queue(j % NSETS, S)
+            if rank == 0 and leg.parts & 4 and state["coadds"]:
+                v = leg.coadded(S, age=1)             # coadded bytes of the batch before
                 state["sink"] += int(v[0])
             state["coadds"] += 1
 
@@ -335,6 +308,8 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
         if world > 1:
             dist.barrier()
 
+    per_rank = []          # N > 1: every rank's own time of each timed region (the line reports min / max over ranks)
+
     def timed_region():
         """EXACTLY `steps` steps between two fences; seconds, MAX over ranks"""
         t0 = time.perf_counter()
@@ -344,8 +319,10 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            per_rank.append([float(x.item()) for x in allt])
+            dt = max(per_rank[-1])
         return dt
 
     for _ in range(warmup):
@@ -357,7 +334,12 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
     fence()
     h.timers(reset=True)
     h.profile(True)
+    per_rank.clear()
+    if leg is not None:
+        leg.reduce_ms()
+        leg.timing = True
     dts = [timed_region() for _ in range(max(1, regions))]
+    red_ms, red_n = leg.reduce_ms() if leg is not None else (0.0, 0)
     gc.enable()
     dt = float(np.median(dts))
     if trace is not None:
@@ -393,10 +375,21 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
                "stage_ms_per_step": {k: round(v[0] / nsteps_timed, 4) for k, v in tm.items() if v[1] > 0}}
         # the whole step against the same peak: compulsory bytes of every kernel that ran (the channeliser that flags
         # its own rows reads the voltages once: no separate kurtosis pass, 256 MB per second of data less than round 2)
+        if world > 1:
+            # the median region as every rank saw it, and the collective's device time on this (the root) rank: a curve
+            # that bends can then be read (a slow rank? the reduce?)
+            med = per_rank[int(np.argsort(dts)[len(dts) // 2])]
+            res["per_rank"] = {"ms_per_step_min": round(min(med) / steps * 1e3, 4), "ms_per_step_max": round(max(med) / steps * 1e3, 4),
+                               "ms_per_step": [round(x / steps * 1e3, 4) for x in med]}
+            res["reduce_leg"] = {"device_ms_per_call_root": round(red_ms / red_n, 4) if red_n else None, "calls": red_n,
+                                 "bytes_per_call": int(S * h.ave_per_seg * 4),
+                                 "note": "event pair around dist.reduce on the leg's stream, beside the next batch's kernels"}
         step_bytes = sum(alg[k] for k in stages) * S * A
         res["roofline"]["pipeline"] = {"algorithmic_bytes_per_step": step_bytes,
                                        "achieved": round(step_bytes / (dt / steps) / 1e9, 1),
                                        "frac": round(step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}
+    if leg is not None:
+        leg.close()
     h.close()
     return res
 
@@ -630,12 +623,21 @@ def main():
             out["rccl_ranks"] = dist.get_world_size()
             out["dist_backend"] = "%s (%s)" % (dist.get_backend(), "RCCL" if args.dist_backend == "nccl" else "rehearsal")
             out["gpus_visible"] = ndev
+            out["per_rank"] = r.get("per_rank")
+            out["reduce_leg"] = r.get("reduce_leg")
+            # one rank per GPU, all of them in the group: anything else is not the run the line claims to be
+            if not args.share_gpus:
+                assert out["rccl_ranks"] == out["n_gpus"] == args.gpus and ndev >= world, (out["rccl_ranks"], out["n_gpus"], ndev)
+            out["ranks_ok"] = bool(out["rccl_ranks"] == out["n_gpus"] and ndev >= world)
         if c3 is not None:
             out["configs3"] = {"antennas": c3["nant_total"], "antennas_per_gpu": 2, "value": round(c3["msamp"], 1),
                                "unit": "Msamp/s", "ms_per_step": round(c3["ms_per_step"], 4),
                                "ms_per_step_cold": round(c3["ms_per_step_cold"], 4), "timed_regions": c3["regions"],
                                "x_realtime_per_antenna": round(c3["msamp"] / c3["nant_total"] / 128.0, 1),
                                "stage_ms_per_step": c3["stage_ms_per_step"],
+                               "per_rank": c3.get("per_rank"), "reduce_leg": c3.get("reduce_leg"),
+                               "product": "vlite-fast_amd/coadd_host.py runs this leg (coadd.IncoherentCoadd) on antenna "
+                                          "dumps / rings and writes the one station-99 .fil",
                                "note": "BASELINE configs[3] (16 antennas on 8 GPUs): %d antennas here, 2 per GPU, fp32 reduce "
                                        "of the locally pre-summed planes to rank 0, which requantises the coadded "
                                        "second" % c3["nant_total"]}

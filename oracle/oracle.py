@@ -229,6 +229,17 @@ def segment(udat, nrows, bp_raw, bp_kur, rfi_mode=2, npol=1, nbit=8, frb_delays=
     return r
 
 
+def sel_and_dig(fft_ave, nrows, npol=1, nbit=8):
+    """K11 alone: the full [(pol)][nrows/8][6251] fp32 plane -> filterbank bytes (orc_sel_and_dig_8b/4b/2b,
+    src/pb_kernels.cu:711-735, :672-708, :633-669).  Used by the coadd tests: the root requantises the summed plane."""
+    fft_ave = np.ascontiguousarray(fft_ave, dtype=np.float32).ravel()
+    assert fft_ave.size == scrunch_len(nrows, npol)
+    out = np.zeros(trim_bytes(nrows, npol, nbit), np.uint8)
+    fn = {8: "orc_sel_and_dig_8b", 4: "orc_sel_and_dig_4b", 2: "orc_sel_and_dig_2b"}[nbit]
+    getattr(lib(), fn)(_f(fft_ave), _u(out), out.size, npol, nrows // 8)
+    return out
+
+
 # --------------------------------------------------------------------------
 # NumPy restatements of the reference's Python analysis code
 

@@ -1,0 +1,190 @@
+"""The coadder host (vlite-fast_amd/coadd_host.py, BASELINE configs[3]) without a GPU: two ranks under gloo, the
+device replaced by a stand-in whose outputs are pure functions of the samples it was given, so that every byte of
+every file can be predicted.  Under test: antenna a -> rank a mod world, streams aligned on their VDIF seconds (one
+antenna starts a second early, one ends a second early), every antenna's own .fil / _kur.fil, the per-second
+incoherent-sum leg through coadd.IncoherentCoadd (local sum -> dist.reduce -> the root's requantisation, collected
+one second late), the single station-99 file with its SIGPROC header and the coadded ring.
+Reference: scripts/start_coadd:16,20-58 (one coadder rank per antenna ring), src/process_baseband.cu:272-285
+(station-99 name), :1416-1422 (coadd ring feed)."""
+import argparse
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R, SEG = 8, 10
+NSEC_SAMP = R * SEG * 12500
+FPS = NSEC_SAMP // 5000
+TRIM = 2 * R * 4096 // 16              # 8-bit, npol 1: bytes per segment == fp32 plane floats per segment
+NANT = 4
+STATIONS = [7, 12, 15, 21]
+
+
+def _mods():
+    return [importlib.import_module("vlite-fast_amd." + m) for m in ("vdif", "sigproc", "dada", "coadd", "coadd_host")]
+
+
+class FakeCoaddHandle(object):
+    """Duck-typed PbHandle(keep_ave=True) with `nant` local antennas: host deframe; codes = the staged samples
+    (pol 0 -> raw stream, pol 1 -> excised stream); fp32 plane = float(excised codes) - 128; pb_coadd_local /
+    pb_coadd_finish act on the caller's buffer through its address, like the library."""
+
+    def __init__(self, nant, nsets=2):
+        self.nant, self.nsets, self.trim, self.max_seg, self.ave_per_seg = nant, nsets, TRIM, SEG, TRIM
+        self.cfg = argparse.Namespace(fft_backend=1)
+        self.cur_set = 0
+        self.staged = [[None] * nant for _ in range(nsets)]
+        self.done = [[None] * nant for _ in range(nsets)]
+        self.co = [None, None]
+        self.co_last = 0
+        self.calls = []
+        self.vdif = importlib.import_module("vlite-fast_amd.vdif")
+
+    def select_set(self, i):
+        self.cur_set = i
+
+    def reset_history(self, ant):
+        pass
+
+    def sync(self):
+        pass
+
+    def set_coadd_stream(self, s):
+        pass
+
+    def submit_vdif(self, ant, seg0, block, second=None, frame0=0):
+        assert self.staged[self.cur_set][ant] is None, "buffer set refilled before it was processed"
+        self.staged[self.cur_set][ant] = self.vdif.deframe_block(np.array(block, copy=True), second, frame0)
+        self.calls.append(("submit", self.cur_set, ant, second))
+
+    def process(self, nseg, inject_now=0):
+        assert all(s is not None for s in self.staged[self.cur_set])
+        self.done[self.cur_set], self.staged[self.cur_set] = self.staged[self.cur_set], [None] * self.nant
+        self.calls.append(("process", self.cur_set))
+
+    def fetch(self, ant, seg0, nseg, raw=True, kur=True, **kw):
+        d = self.done[self.cur_set][ant]
+        return dict(raw=d[0, :nseg * TRIM].copy() if raw else None, kur=d[1, :nseg * TRIM].copy() if kur else None)
+
+    def _mem(self, ptr, n):
+        return np.ctypeslib.as_array((C.c_float * n).from_address(ptr))
+
+    def coadd_local(self, nseg, ptr, accumulate=False):
+        m = self._mem(ptr, nseg * TRIM)
+        s = np.zeros(nseg * TRIM, np.float32)
+        for a in range(self.nant):
+            s = s + (self.done[self.cur_set][a][1, :nseg * TRIM].astype(np.float32) - np.float32(128))
+        m[:] = s
+        self.calls.append(("coadd_local", self.cur_set))
+
+    def coadd_finish(self, nseg, ptr, nant_total, blocking=True):
+        m = self._mem(ptr, nseg * TRIM)
+        v = m * np.float32(1.0 / np.sqrt(float(nant_total))) + np.float32(128)
+        slot = self.co_last ^ 1
+        self.co[slot] = np.clip(v, 0, 255).astype(np.uint8)
+        self.co_last = slot
+
+    def coadd_view(self, nseg, age=0):
+        return self.co[self.co_last if age == 0 else self.co_last ^ 1]
+
+    def close(self):
+        pass
+
+
+def _second(ant, sec):
+    p0 = synth.baseband_u8(9000 + 100 * ant + 2 * (sec - 3590), NSEC_SAMP)
+    p1 = synth.baseband_u8(9001 + 100 * ant + 2 * (sec - 3590), NSEC_SAMP)
+    p0[p0 == 0] = 1
+    p1[p1 == 0] = 1
+    return p0, p1
+
+
+def _seconds_of(ant):
+    """antenna 1 starts one second early, antenna 2 ends one second early"""
+    first = 3599 if ant == 1 else 3600
+    last = 3602 if ant == 2 else 3603
+    return list(range(first, last + 1))
+
+
+def _stream(ant):
+    vdif = importlib.import_module("vlite-fast_amd.vdif")
+    secs = _seconds_of(ant)
+    hdr = vdif.ascii_header_format(vdif.writer_header(STATIONS[ant], 0.8718, -0.72452, "B0833-45", 58000.0, "19A-331", 33, secs[0]))
+    body = b"".join(vdif.frame_block(*_second(ant, s), s, 33, STATIONS[ant]).tobytes() for s in secs)
+    return hdr, body
+
+
+def _worker(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    vdif, sigproc, dada, coadd, host = _mods()
+    args = host.build_parser().parse_args(["--replay"] + ["unused"] * NANT + ["-b", "8", "-r", "2", "-w", "2", "--datadir", tmp,
+                                           "--logdir", os.path.join(tmp, "logs"), "--rows-per-seg", str(R),
+                                           "--dist-backend", "gloo", "--out-sink", os.path.join(tmp, "co_ring.bin")])
+    mine = coadd.antennas_of_rank(NANT, rank, world)
+    rings = {}
+    for a in mine:
+        hdr, body = _stream(a)
+        r = dada.MemoryRing()
+        r.write_header(hdr)
+        r.write(np.frombuffer(body, np.uint8))
+        r.end_of_data()
+        rings[a] = r
+    h = FakeCoaddHandle(len(mine), nsets=2)
+    co = coadd.IncoherentCoadd(h, NANT, torch.device("cpu"), root=0, backend="gloo")
+    rc = host.run(args, rank=rank, world=world, local=0, rings=rings, handle=h, dist=dist, device=torch.device("cpu"), coadd=co)
+    with open(os.path.join(tmp, "rc%d" % rank), "w") as f:
+        f.write("%d %s" % (rc, [c for c in h.calls if c[0] == "submit"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_coadd_host_world2_files_and_sum(tmp_path):
+    os.environ["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"),
+                                                os.environ.get("PYTHONPATH", "")])
+    ctx = mp.get_context("spawn")
+    port = 29900 + os.getpid() % 2000
+    tmp = str(tmp_path)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, tmp)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    vdif, sigproc, dada, coadd, host = _mods()
+    for r in range(2):
+        txt = (tmp_path / ("rc%d" % r)).read_text()
+        assert txt.startswith("0 ")
+    # the sum covers seconds 3600 and 3601: antenna 1's early second is skipped, antenna 2's stream ends with 3602,
+    # which -- being its last -- is dropped
+    secs = [3600, 3601]
+    dmjd = 57570 + 3600 / 86400.
+    planes = []
+    for a in range(NANT):
+        hdr = sigproc.sigproc_header(STATIONS[a], 0.8718, -0.72452, "B0833-45", dmjd, 1, 8)
+        raw = b"".join(_second(a, s)[0][:SEG * TRIM].tobytes() for s in secs)
+        kur = b"".join(_second(a, s)[1][:SEG * TRIM].tobytes() for s in secs)
+        assert (tmp_path / ("20160701_010000_muos_ea%02d.fil" % STATIONS[a])).read_bytes() == hdr + raw, a
+        assert (tmp_path / ("20160701_010000_muos_ea%02d_kur.fil" % STATIONS[a])).read_bytes() == hdr + kur, a
+        planes.append(np.concatenate([_second(a, s)[1][:SEG * TRIM] for s in secs]).astype(np.float32) - np.float32(128))
+    # rank 0 holds antennas 0 and 2, rank 1 antennas 1 and 3; fp32 sums in that order, 1 / sqrt(4)
+    tot = ((np.float32(0) + planes[0]) + planes[2]) + ((np.float32(0) + planes[1]) + planes[3])
+    want = np.clip(tot * np.float32(0.5) + np.float32(128), 0, 255).astype(np.uint8).tobytes()
+    co_hdr = sigproc.sigproc_header(99, 0.8718, -0.72452, "B0833-45", dmjd, 1, 8)
+    assert (tmp_path / "20160701_010000_muos_ea99_kur.fil").read_bytes() == co_hdr + want
+    ring = (tmp_path / "co_ring.bin").read_bytes()
+    rh = vdif.ascii_header_parse(ring[:4096])
+    assert rh["STATIONID"] == "99" and rh["SIGPROC_FILE"].endswith("_muos_ea99_kur.fil") and rh["NBIT"] == "8"
+    assert ring[4096:] == want
+    # every rank submitted its own antennas only, second by second in lockstep
+    sub0 = eval((tmp_path / "rc0").read_text().split(" ", 1)[1])
+    assert [(c[2], c[3]) for c in sub0] == [(0, 3600), (1, 3600), (0, 3601), (1, 3601)]

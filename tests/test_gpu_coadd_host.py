@@ -1,0 +1,108 @@
+"""BASELINE configs[3] end to end on the GPU: the coadder host (vlite-fast_amd/coadd_host.py) started as TWO ranks
+(`--ranks 2`, gloo rehearsal back end, both ranks on the one GPU this pool hands out), FOUR antenna dumps, two
+antennas per rank batched in one handle -- pb_submit_vdif -> pb_process -> pb_coadd_local -> dist.reduce ->
+pb_coadd_finish on the root -- against the oracle:
+  * every antenna's own .fil / _kur.fil byte for byte = header + the oracle's codes of that antenna's data;
+  * the ONE coadded file `..._ea99_kur.fil` byte for byte = the station-99 SIGPROC header +
+    sel_and_dig_8b( ((ave_kur_0 + ave_kur_2) + (ave_kur_1 + ave_kur_3)) * float(1/sqrt 4) ) of the oracle's fp32
+    excised planes (rank 0 holds antennas 0 and 2, rank 1 antennas 1 and 3; fp32 sums in that order);
+  * the coadded ring stand-in carries the same bytes behind a header naming that file.
+(With RCCL the same code runs `dist.reduce` on the device buffers; more than one RCCL rank needs more than one GPU.)
+Reference: scripts/start_coadd:16,20-58; src/process_baseband.cu:272-285,1416-1422."""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import make_input, oracle_run
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+vdif = importlib.import_module("vlite-fast_amd.vdif")
+sigproc = importlib.import_module("vlite-fast_amd.sigproc")
+
+R, SEG = 8, 10
+NANT = 4
+STATIONS = [3, 8, 11, 27]
+
+
+def _dump(path, data, station):
+    nsec = data.shape[0] // SEG
+    hdr = vdif.writer_header(station, 0.8718, -0.72452, "B0833-45", 58000.0, "19A-331", 33, 3600)
+    with open(path, "wb") as f:
+        f.write(vdif.ascii_header_format(hdr))
+        for s in range(nsec):
+            p0 = np.concatenate([data[s * SEG + i, 0] for i in range(SEG)])
+            p1 = np.concatenate([data[s * SEG + i, 1] for i in range(SEG)])
+            f.write(vdif.frame_block(p0, p1, 3600 + s, 33, station).tobytes())
+
+
+@pytest.mark.parametrize("nbit", [8, 2])
+def test_two_ranks_four_antennas_coadded_fil_is_byte_exact(tmp_path, oracle, nbit):
+    nsec = 4                                         # -> 3 s out (the last second of every stream is dropped)
+    data = [make_input(80 + a, R, nsec * SEG, rfi=a != 1, dropped=a == 2) for a in range(NANT)]
+    dumps = []
+    for a in range(NANT):
+        p = str(tmp_path / ("ant%d.uw" % a))
+        _dump(p, data[a], STATIONS[a])
+        dumps.append(p)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.join(ROOT, "vlite-fast_amd", "coadd_host.py"), "--ranks", "2", "--dist-backend", "gloo",
+           "--share-gpus", "--replay"] + dumps + ["-b", str(nbit), "-r", "2", "-w", "2", "--datadir", str(tmp_path),
+           "--logdir", str(tmp_path / "logs"), "--rows-per-seg", str(R), "--out-sink", str(tmp_path / "co_ring.bin")]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    nseg = (nsec - 1) * SEG
+    dmjd = 57570 + 3600 / 86400.
+    planes = []
+    for a in range(NANT):
+        res, _, _ = oracle_run(oracle, data[a][:nseg], R, rfi_mode=2, npol=1, nbit=nbit)
+        hdr = sigproc.sigproc_header(STATIONS[a], 0.8718, -0.72452, "B0833-45", dmjd, 1, nbit)
+        fb = tmp_path / ("20160701_010000_muos_ea%02d.fil" % STATIONS[a])
+        fbk = tmp_path / ("20160701_010000_muos_ea%02d_kur.fil" % STATIONS[a])
+        assert fb.read_bytes() == hdr + b"".join(x.codes_raw.tobytes() for x in res), "antenna %d raw" % a
+        assert fbk.read_bytes() == hdr + b"".join(x.codes_kur.tobytes() for x in res), "antenna %d excised" % a
+        planes.append([x.ave_kur for x in res])
+    scale = np.float32(1.0 / np.sqrt(float(NANT)))
+    want = b""
+    for s in range(nseg):
+        tot = ((np.float32(0) + planes[0][s]) + planes[2][s]) + ((np.float32(0) + planes[1][s]) + planes[3][s])
+        want += oracle.sel_and_dig(tot * scale, R, npol=1, nbit=nbit).tobytes()
+    co_hdr = sigproc.sigproc_header(99, 0.8718, -0.72452, "B0833-45", dmjd, 1, nbit)
+    co = (tmp_path / "20160701_010000_muos_ea99_kur.fil").read_bytes()
+    assert co[:len(co_hdr)] == co_hdr
+    got = np.frombuffer(co[len(co_hdr):], np.uint8)
+    assert got.size == len(want)
+    assert co[len(co_hdr):] == want, "%d coadded bytes differ" % int((got != np.frombuffer(want, np.uint8)).sum())
+    ring = (tmp_path / "co_ring.bin").read_bytes()
+    rh = vdif.ascii_header_parse(ring[:4096])
+    assert rh["STATIONID"] == "99" and rh["SIGPROC_FILE"].endswith("_muos_ea99_kur.fil") and rh["NBIT"] == str(nbit)
+    assert ring[4096:] == want
+    # the coadded stream is not any single antenna's
+    assert want != b"".join(oracle.sel_and_dig(planes[0][s], R, nbit=nbit).tobytes() for s in range(nseg))
+
+
+def test_single_rank_coadd_of_two_antennas_equals_two_rank_sum(tmp_path, oracle):
+    """One rank holding both antennas (local sum only, no collective): the same host, world size 1."""
+    nsec = 3
+    data = [make_input(90 + a, R, nsec * SEG) for a in range(2)]
+    dumps = []
+    for a in range(2):
+        p = str(tmp_path / ("ant%d.uw" % a))
+        _dump(p, data[a], STATIONS[a])
+        dumps.append(p)
+    cmd = [sys.executable, os.path.join(ROOT, "vlite-fast_amd", "coadd_host.py"), "--replay"] + dumps + [
+        "-b", "8", "-r", "2", "-w", "0", "--datadir", str(tmp_path), "--logdir", str(tmp_path / "logs"), "--rows-per-seg", str(R)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    nseg = (nsec - 1) * SEG
+    planes = [[x.ave_kur for x in oracle_run(oracle, data[a][:nseg], R)[0]] for a in range(2)]
+    scale = np.float32(1.0 / np.sqrt(2.0))
+    want = b"".join(oracle.sel_and_dig(((np.float32(0) + planes[0][s]) + planes[1][s]) * scale, R).tobytes() for s in range(nseg))
+    co_hdr = sigproc.sigproc_header(99, 0.8718, -0.72452, "B0833-45", 57570 + 3600 / 86400., 1, 8)
+    assert (tmp_path / "20160701_010000_muos_ea99_kur.fil").read_bytes() == co_hdr + want
+    assert not (tmp_path / ("20160701_010000_muos_ea%02d.fil" % STATIONS[0])).exists()      # -w 0

@@ -93,3 +93,67 @@ def test_fullsize_lds_fft_vs_hipfft():
         d = np.abs(out["lds"][k].astype(int) - out["hipfft"][k].astype(int))
         assert d.max() <= 1, k
         assert (d != 0).mean() < 2e-3, (k, (d != 0).mean())
+
+
+def _run_pipelined_fullsize(lp, data, nant, nsets, nseg, nb):
+    """bench.py's loop: batch b into set b mod nsets (re-staged from the host every time), processed, collected
+    nsets - 1 batches late.  data[ant]: u8 [nb * nseg][2][n].  -> per antenna (raw, kur) codes + bandpass"""
+    got = [{"raw": [], "kur": []} for _ in range(nant)]
+
+    def collect(h, b):
+        h.select_set(b % nsets)
+        for a in range(nant):
+            got[a]["raw"].append(h.fetch_view(a, 0, nseg).copy())
+            got[a]["kur"].append(h.fetch_view(a, 1, nseg).copy())
+
+    with lp.PbHandle(nant=nant, nbit=8, rfi_mode=2, rows_per_seg=R, max_seg=nseg, nsets=nsets) as h:
+        for b in range(nb):
+            h.select_set(b % nsets)
+            for a in range(nant):
+                for s in range(nseg):
+                    h.submit_planar(a, s, data[a][b * nseg + s, 0], data[a][b * nseg + s, 1])
+            h.process(nseg)
+            if b >= nsets - 1:
+                collect(h, b - (nsets - 1))
+        for b in range(max(0, nb - (nsets - 1)), nb):
+            collect(h, b)
+        bps = [h.get_bandpass(a) for a in range(nant)]
+    return got, bps
+
+
+def _assert_equals_oracle(oracle, data, got, bps):
+    from helpers import NCHAN, oracle_run
+    res, bp_raw, bp_kur = oracle_run(oracle, data, R, rfi_mode=2, npol=1, nbit=8)
+    assert np.array_equal(np.concatenate(got["raw"]), np.concatenate([r.codes_raw for r in res])), "raw codes"
+    assert np.array_equal(np.concatenate(got["kur"]), np.concatenate([r.codes_kur for r in res])), "excised codes"
+    assert np.array_equal(bps[0].view(np.uint32), bp_raw.reshape(2, NCHAN)[:, 2155:].view(np.uint32)), "raw bandpass"
+    assert np.array_equal(bps[1].view(np.uint32), bp_kur.reshape(2, NCHAN)[:, 2155:].view(np.uint32)), "excised bandpass"
+    assert (np.concatenate(got["kur"]) != np.concatenate(got["raw"])).any()
+
+
+def test_fullsize_headline_path_as_benchmarked_bit_exact_vs_oracle(oracle):
+    """The headline configuration exactly as bench.py runs it: R = 1024, THREE buffer sets (-> the channeliser that
+    flags its own rows, k_channelize_kur, and detect with three chunks in flight, k_detect2<32,1,8,2,3>), four
+    batches of two segments re-staged into the reused sets (batch 3 goes into set 0 again while batches 1 and 2 are
+    in flight), collected two batches late.  Raw + excised codes and the bandpass state equal the oracle's serial
+    run over the same eight segments (src/process_baseband.cu:1108-1376 order), RFI bursts, a weight-0 row, a
+    strongly flagged row and a dropped frame included."""
+    from helpers import make_input
+    lp = libpb()
+    nsets, nseg, nb = 3, 2, 4
+    d = make_input(43, R, nseg * nb)
+    got, bps = _run_pipelined_fullsize(lp, [d], 1, nsets, nseg, nb)
+    _assert_equals_oracle(oracle, d, got[0], bps[0])
+
+
+def test_fullsize_two_antennas_per_gpu_bit_exact_vs_oracle(oracle):
+    """BASELINE configs[3]'s per-GPU shape at full size: TWO antennas batched in one handle (-> detect's DEPTH 2
+    branch, grid z = 2), three buffer sets, three batches of one segment each: every antenna's codes and bandpass
+    equal the oracle's run over that antenna's own data."""
+    from helpers import make_input
+    lp = libpb()
+    nsets, nseg, nb = 3, 1, 3
+    d = [make_input(44, R, nseg * nb), make_input(45, R, nseg * nb, dropped=False)]
+    got, bps = _run_pipelined_fullsize(lp, d, 2, nsets, nseg, nb)
+    for a in range(2):
+        _assert_equals_oracle(oracle, d[a], got[a], bps[a])

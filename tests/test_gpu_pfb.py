@@ -115,7 +115,7 @@ def test_pfb_weights_and_excision(oracle):
 
 # ---------------------------------------------------------------------------------------------------------
 # The taps = 4 configuration AS BENCHMARKED: two buffer sets (batches pipelined over the library's streams, the
-# history of batch k kept behind ev_hist), RFI mode 2 (both streams; excision zeroes the flagged blocks of every
+# the history kernel of batch k recorded in ev_hist, which the next batch's weights wait for), RFI mode 2 (both streams; excision zeroes the flagged blocks of every
 # contributing row and the row weight is the unflagged fraction of the window's energy), R = 1024 (the XCD-aware
 # row mapping of k_channelize_pfb).  The oracle is the reference's kernels composed around the same fp32 FIR.
 
@@ -207,9 +207,11 @@ def _oracle_pfb_chain_mode2(oracle, data, Rr):
     return np.concatenate(codes_raw), np.concatenate(codes_kur), w, flags
 
 
-def _run_pipelined(lp, batches, Rr, rfi_mode, nsets):
+def _run_pipelined(lp, batches, Rr, rfi_mode, nsets, resident=False):
     """bench.py's order of calls: batch k goes to buffer set k mod nsets (re-staged every time), its bytes are
-    collected nsets - 1 batches later"""
+    collected nsets - 1 batches later.  resident (needs len(batches) <= nsets): every batch is staged into its set
+    and the device is idle before the first pb_process, then the batches are processed back to back with no staging
+    between them -- bench.py's HBM-resident input: nothing but the library's own events orders the kernels."""
     S = batches[0].shape[0]
     raw, kur, wts = [], [], []
 
@@ -221,10 +223,18 @@ def _run_pipelined(lp, batches, Rr, rfi_mode, nsets):
         wts.append(o["weights"])
 
     with lp.PbHandle(nbit=8, rfi_mode=rfi_mode, taps=4, rows_per_seg=Rr, max_seg=S, nsets=nsets) as h:
+        if resident:
+            assert len(batches) <= nsets
+            for k, d in enumerate(batches):
+                h.select_set(k)
+                for s in range(S):
+                    h.submit_planar(0, s, d[s, 0], d[s, 1])
+            h.sync()
         for k, d in enumerate(batches):
             h.select_set(k % nsets)
             for s in range(S):
-                h.submit_planar(0, s, d[s, 0], d[s, 1])
+                if not resident:
+                    h.submit_planar(0, s, d[s, 0], d[s, 1])
             h.process(S)
             if k >= nsets - 1:
                 collect(h, k - (nsets - 1))
@@ -234,8 +244,8 @@ def _run_pipelined(lp, batches, Rr, rfi_mode, nsets):
 
 
 def test_pfb_pipelined_two_sets_mode0_bit_exact(oracle):
-    """(a) nsets = 2, four batches re-staged into the reused sets: the carried rows of batch k (history kernel behind
-    ev_hist) reach batch k + 1 although its input was staged while batch k was still running."""
+    """(a) nsets = 2, four batches re-staged into the reused sets: the carried rows of batch k (its history kernel,
+    recorded in ev_hist) reach batch k + 1 although its input was staged while batch k was still running."""
     lp = libpb()
     S, NB = 2, 4
     data = make_input(61, R, S * NB, rfi=False, dropped=False)
@@ -271,6 +281,34 @@ def test_pfb_rfi_mode2_both_streams_bit_exact(oracle, nsets):
     assert np.array_equal(np.concatenate(raw), ref_raw), "raw-stream codes differ"
     assert np.array_equal(np.concatenate(kur), ref_kur), "excised-stream codes differ"
     assert (ref_kur != ref_raw).any()
+
+
+def test_pfb_three_sets_resident_input_history_ordering(oracle):
+    """Three buffer sets with the input already on the device (no staging between the pb_process calls, as in
+    bench.py): batch 0's history kernel runs on the main stream, batch 1's kurtosis pass and PFB weights on the
+    kurtosis stream without waiting for batch 0's channeliser -- only ev_hist orders the weights of batch 1's first
+    three rows behind the history kernel that keeps batch 0's last flags (with staging in between, the copies hid
+    the missing order).  Flags in batch 0's last rows make those weights differ from "nothing flagged" and from the
+    memset state "everything flagged"."""
+    lp = libpb()
+    S, NB = 2, 3
+    data = make_input(64, R, S * NB)
+    for b in (0, 1):                      # RFI in the last two rows of batches 0 and 1, one block each pol
+        seg = b * S + S - 1
+        for row, blk in ((R - 1, 7), (R - 2, 19)):
+            x = data[seg, 0, row * NFFT + blk * 500:row * NFFT + (blk + 1) * 500]
+            x[:] = np.where((np.arange(500) // 5) % 2 == 0, 230, 26)
+    ref_raw, ref_kur, w, flags = _oracle_pfb_chain_mode2(oracle, data, R)
+    assert flags[S * R - 1].any() and flags[S * R - 2].any()
+    first3 = w[S * R:S * R + 3]
+    assert ((first3 > 0) & (first3 < 1)).all()
+    batches = [data[k * S:(k + 1) * S] for k in range(NB)]
+    raw, kur, wts = _run_pipelined(lp, batches, R, 2, 3, resident=True)
+    gw = np.concatenate(wts)
+    expect_w = np.where(w >= np.float32(0.2), w, np.float32(0))
+    assert np.array_equal(gw.view(np.uint32), expect_w.view(np.uint32)), "window-energy weights differ"
+    assert np.array_equal(np.concatenate(raw), ref_raw), "raw-stream codes differ"
+    assert np.array_equal(np.concatenate(kur), ref_kur), "excised-stream codes differ"
 
 
 def test_pfb_fullsize_two_segments_mode2_bit_exact(oracle):

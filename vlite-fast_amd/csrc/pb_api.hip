@@ -381,7 +381,14 @@ static int create_impl(pb_handle *h)
     }
     h->dag = make_dag((float)PB_NKURTO);
     h->dag_fb = make_dag((float)PB_NFFT);
-    if (int rcb = find_dag_bands(h, h->dag)) return rcb;
+    if (int rcb = find_dag_bands(h, h->dag)) {
+        // The bands only save work (the score is then evaluated in a few floats around the crossings instead of
+        // everywhere): if the search does not bracket the crossings -- host and device disagreeing by more than the
+        // scanned window -- fall back to "no bands", where the score itself decides every flag.  A HIP error is fatal.
+        if (rcb != PB_ESTATE) return rcb;
+        h->dag = make_dag((float)PB_NKURTO);
+        h->err.clear();
+    }
     // (a copy in device memory for the channeliser that flags its own rows: ten fewer scalar registers of arguments)
     HIPCHK(h, hipMalloc((void **)&h->d_dag, sizeof(DagConsts)));
     HIPCHK(h, hipMemcpy(h->d_dag, &h->dag, sizeof(DagConsts), hipMemcpyHostToDevice));
@@ -574,14 +581,14 @@ static hipError_t submit_stream(pb_handle *h, hipStream_t *out)
     }
     // hipFFT back end: its kurtosis pass (the last reader of d_in) runs on the MAIN stream, which s_kur is
     // not ordered behind: staging batch k+2 into this set must wait for the latest FFT stage, which is
-    // queued behind every earlier reader of this set's input.  (LDS back end: kurtosis and the channeliser
-    // of this set ran two batches ago behind s_kur -> ev_kur -> main -> ev_fftdone -> s_kur of the batch
-    // between, so the order already holds and staging overlaps the running channeliser.)
+    // queued behind every earlier reader of this set's input.
     if (h->cfg.fft_backend == PB_FFT_HIPFFT && h->last_set >= 0) return hipStreamWaitEvent(h->s_kur, h->ev_fftdone, 0);
-    // Fused kurtosis: no kernel runs on s_kur any more, so nothing orders it behind the channeliser that read this
-    // set's input last (two batches ago, on the main stream).  This set's ev_chan (its detect is done, queued
-    // behind that channeliser) does: it completed while the batch in between was being channelised.
-    if (pb_fused_kurtosis(h) && h->processed > 0) return hipStreamWaitEvent(h->s_kur, h->ev_chan, 0);
+    // In-library FFT: s_kur is not in general ordered behind the channeliser that read this set's input last, on
+    // the main stream (the channeliser that flags its own rows leaves s_kur empty; with three or more sets the
+    // kurtosis pass of the two-kernel path no longer waits for the previous channeliser either).  This set's
+    // ev_chan -- its detect is done, queued behind that channeliser and, with taps = 4, behind the history kernel
+    // that read the set's last rows -- does, and it completed while the batches in between were being channelised.
+    if (h->processed > 0) return hipStreamWaitEvent(h->s_kur, h->ev_chan, 0);
     return hipSuccess;
 }
 
@@ -925,6 +932,10 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
             }
             // taps = 4: the weights read the flags of the previous batch's last rows (history slot hist_rd, filled by
             // that batch's history kernel earlier on this stream).
+            // ... or on the main stream, when that batch was not on the overlap path (the first batch, a batch that
+            // repeated its set): ev_hist, recorded behind every history kernel on whichever stream ran it, orders the
+            // weights behind it either way (free when both are on this stream).
+            if (e == hipSuccess && h->cfg.taps == 4) e = hipStreamWaitEvent(h->stream, h->ev_hist, 0);
             if (e == hipSuccess) e = launch_pfb_weights(h, nseg);
             if (e == hipSuccess && h->cfg.taps == 4) {
                 // The channeliser only needs what has been queued up to here: release it now.  Then keep this
@@ -936,6 +947,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
                 if (overlap) e = hipEventRecord(h->ev_kur, h->s_kur);
                 if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->ev_fftdone, 0);
                 if (e == hipSuccess) e = launch_pfb_history(h, nseg);
+                if (e == hipSuccess) e = hipEventRecord(h->ev_hist, h->stream);
             }
         }
         if (overlap) {

@@ -61,12 +61,13 @@ const char *DEF_DATADIR = "/mnt/ssd/fildata";             // src/def.h:28
 // lines `name <substring of NAME>` / `dataid <substring of DATAID>`; no file: -w 1 writes nothing
 struct WriteAllow {
     std::vector<std::string> names, ids;
-    bool loaded = false;
+    std::vector<std::pair<double, double>> coords;     // `coords <ra> <dec>` [rad], check_coords (src/util.c:136-152)
+    std::string path;
+    bool loaded = false, ok = false;
     void load()
     {
         if (loaded) return;
         loaded = true;
-        std::string path;
         if (const char *e = getenv("PB_WRITE_ALLOW")) path = e;
         else {
             char self[4096];
@@ -78,10 +79,13 @@ struct WriteAllow {
         }
         FILE *f = fopen(path.c_str(), "r");
         if (!f) return;
+        ok = true;
         char line[512];
         while (fgets(line, sizeof line, f)) {
             if (char *h = strchr(line, '#')) *h = 0;
             char key[32], val[256];
+            double ra, de;
+            if (sscanf(line, "%31s %lf %lf", key, &ra, &de) == 3 && !strcmp(key, "coords")) { coords.push_back({ra, de}); continue; }
             if (sscanf(line, "%31s %255s", key, val) != 2) continue;
             if (!strcmp(key, "name")) names.push_back(val);
             else if (!strcmp(key, "dataid")) ids.push_back(val);
@@ -559,10 +563,16 @@ bool test_for_cmd(int sock, char cmd)
     return false;
 }
 
+// src/process_baseband.cu:893-913: position, then NAME, then DATAID (check_coords / check_name / check_id)
 bool source_allowed(const std::map<std::string, std::string> &hdr)
 {
     const std::string name = get(hdr, "NAME"), id = get(hdr, "DATAID");
     g_allow.load();
+    const double ra = atof(get(hdr, "RA").c_str()), dec = atof(get(hdr, "DEC").c_str());
+    for (const auto &c : g_allow.coords) {
+        const double dde = dec - c.second, dra = (ra - c.first) * cos(c.second);      // coord_dist, src/util.c:127-134
+        if (sqrt(dde * dde + dra * dra) < 0.01) return true;
+    }
     for (const std::string &n : g_allow.names)
         if (name.find(n) != std::string::npos) return true;
     for (const std::string &n : g_allow.ids)
@@ -575,7 +585,8 @@ void usage()
     puts("usage: process_baseband -k <key_in hex> -K <key_out hex> -C <key_co hex> -w <0|1|2> -b <2|4|8> -P <1|2>\n"
          "       -r <0|1|2> -g <gpu> [-o] [-i] [-s] [-t] [-m] [-p N]\n"
          "       [--replay FILE...] [--out-sink FILE] [--co-sink FILE] [--datadir DIR] [--logdir DIR] [--no-control]\n"
-         "       [--fft-backend lds|hipfft] [--taps 1|4] [--rows-per-seg N] [--dump-headers]");
+         "       [--fft-backend lds|hipfft] [--taps 1|4] [--rows-per-seg N] [--dump-headers]\n"
+         "       process_baseband --check-source NAME DATAID RA DEC");
 }
 
 bool parse(int argc, char **argv, Args &a)
@@ -761,6 +772,12 @@ int run(const Args &args)
         }
         bool write_to_null = args.write_fb == 0;
         if (args.write_fb == 1) {
+            g_allow.load();
+            if (g_allow.ok)
+                log.line(false, "Source list for -w 1: %s (%zu names, %zu dataids, %zu positions).", g_allow.path.c_str(),
+                         g_allow.names.size(), g_allow.ids.size(), g_allow.coords.size());
+            else
+                log.line(true, "Source list for -w 1 not usable (%s): no source will be recorded.", g_allow.path.c_str());
             if (source_allowed(hdr))
                 log.line(false, "Source %s matches target list, recording filterbank data.", get(hdr, "NAME").c_str());
             else {
@@ -974,6 +991,13 @@ int run(const Args &args)
 
 int main(int argc, char **argv)
 {
+    // --check-source NAME DATAID RA DEC: the -w 1 decision for one header (prints 1 or 0; no GPU, no rings) -- what
+    // the reference's check_coords / check_name / check_id answer (tests/test_ref_util.py compares)
+    if (argc == 6 && !strcmp(argv[1], "--check-source")) {
+        std::map<std::string, std::string> hdr{{"NAME", argv[2]}, {"DATAID", argv[3]}, {"RA", argv[4]}, {"DEC", argv[5]}};
+        printf("%d\n", source_allowed(hdr) ? 1 : 0);
+        return 0;
+    }
     Args args;
     if (!parse(argc, argv, args)) {
         usage();

@@ -184,6 +184,7 @@ class PbHandle(object):
         self.rows = int(s.rows_per_seg)
         self.nblk = int(s.blocks_per_seg_pol)
         self.nant, self.max_seg, self.nsets = nant, max_seg, nsets
+        self.cur_set = 0
 
     def _chk(self, rc):
         if rc != 0:
@@ -244,6 +245,7 @@ class PbHandle(object):
 
     def select_set(self, i):
         self._chk(self._L.pb_select_set(self._h, i))
+        self.cur_set = i
 
     def fetch_view(self, ant, stream, nseg):
         """Zero-copy numpy view of the selected set's codes in pinned host memory."""

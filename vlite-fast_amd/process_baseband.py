@@ -46,10 +46,11 @@ LOGDIR = "/home/vlite-master/mtk/logs"                # src/def.h:26
 WRITE_ALLOW_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "site", "write_allow.txt")
 
 
-def load_write_allow(path=None):
-    """-> (NAME substrings, DATAID substrings); both empty when there is no file"""
+def load_write_allow(path=None, log=None):
+    """-> (NAME substrings, DATAID substrings, (ra, dec) positions [rad]); all empty when there is no file -- said
+    in the log, with the path that was tried, so that `-w 1` never drops data silently"""
     path = path or os.environ.get("PB_WRITE_ALLOW") or WRITE_ALLOW_FILE
-    names, ids = [], []
+    names, ids, coords = [], [], []
     try:
         with open(path) as f:
             for line in f:
@@ -58,9 +59,25 @@ def load_write_allow(path=None):
                     names.append(t[1])
                 elif len(t) == 2 and t[0] == "dataid":
                     ids.append(t[1])
-    except OSError:
-        pass
-    return tuple(names), tuple(ids)
+                elif len(t) == 3 and t[0] == "coords":
+                    coords.append((float(t[1]), float(t[2])))
+        if log:
+            log("INFO", "Source list for -w 1: %s (%d names, %d dataids, %d positions)." % (path, len(names), len(ids), len(coords)))
+    except (OSError, ValueError) as e:
+        if log:
+            log("ERR", "Source list for -w 1 not usable (%s: %s): no source will be recorded." % (path, e))
+    return tuple(names), tuple(ids), tuple(coords)
+
+
+COORD_TOL = 0.01      # check_coords' default tolerance [rad], src/util.h
+
+
+def coord_dist(ra1, ra2, de1, de2):
+    """src/util.c:127-134 (radians)"""
+    import math
+    dde = de2 - de1
+    dra = (ra2 - ra1) * math.cos(de1)
+    return math.sqrt(dde * dde + dra * dra)
 
 
 def build_parser():
@@ -165,11 +182,97 @@ def test_for_cmd(sock, cmd):
 
 
 def source_allowed(hdr, allow=None):
-    names, ids = allow if allow is not None else load_write_allow()
+    """src/process_baseband.cu:893-913: position, then NAME, then DATAID (check_coords / check_name / check_id)"""
+    allow = allow if allow is not None else load_write_allow()
+    names, ids = allow[0], allow[1]
+    coords = allow[2] if len(allow) > 2 else ()
+    try:
+        ra, dec = float(hdr.get("RA", 0)), float(hdr.get("DEC", 0))
+    except ValueError:
+        ra = dec = 0.0
+    if any(coord_dist(cra, ra, cde, dec) < COORD_TOL for cra, cde in coords):
+        return True
     name = hdr.get("NAME", "")
     if any(n in name for n in names):
         return True
     return any(i in hdr.get("DATAID", "") for i in ids)
+
+
+class SecondReader(object):
+    """The frames of one observation, one second at a time (src/process_baseband.cu:1015-1067).
+
+    Frames are placed by their own headers (thread id, frame number: :1017-1034), a second is closed by the
+    first frame of another second (:1019, :1058) and handed on only then -- so the last second of an
+    observation is dropped -- and a frame that never arrives leaves zeros.  The frames of one second are
+    gathered in a page-locked block in bulk; when frames were dropped the block swallows the head of the next
+    second, which is carried over, so that the stream re-aligns at once (the reference loses the dropped frame
+    and nothing else).  Shared by process_baseband's loop and the coadder host (one reader per antenna)."""
+
+    def __init__(self, ring, first, sec_bytes, log):
+        self.ring, self.sec_bytes, self.log = ring, sec_bytes, log
+        self.readinto = getattr(ring, "readinto", None)
+        self.carry = bytes(first)          # frames of the second being assembled that have been read already
+        self.current_sec = vdif.unpack_header(first)["second"]
+        self.boundary = None
+
+    def fill(self, block):
+        """Assemble second `current_sec` in `block`.  -> (have, next_header): bytes of this second in the block
+        (frames of other seconds behind them are marked invalid) and the header of the first frame of the next
+        second; (None, None) at the end of data (the last, partial or whole, second is dropped)."""
+        ring, sec_bytes, current_sec = self.ring, self.sec_bytes, self.current_sec
+        have = len(self.carry)
+        block[:have] = np.frombuffer(self.carry, np.uint8)
+        self.carry = b""
+        boundary = None    # bytes (>= one frame) of the next second, already read
+        eod = False
+        while boundary is None and not eod:
+            if have < sec_bytes:
+                if self.readinto is not None:
+                    got = self.readinto(block[have:]) or 0
+                else:
+                    rest = ring.read(sec_bytes - have)
+                    got = len(rest)
+                    block[have:have + got] = np.frombuffer(rest, np.uint8)
+                if got % vdif.VD_FRM:
+                    self.log("INFO", "Packet size=%d, expected %d.  Aborting this observation."
+                             % (got % vdif.VD_FRM, vdif.VD_FRM))
+                    got -= got % vdif.VD_FRM
+                    eod = True
+                elif got < sec_bytes - have:
+                    eod = True
+                have += got
+            else:
+                nxt = ring.read(vdif.VD_FRM)     # block full and all of this second: the next frame decides
+                if len(nxt) != vdif.VD_FRM:
+                    if len(nxt):
+                        self.log("INFO", "Packet size=%d, expected %d.  Aborting this observation." % (len(nxt), vdif.VD_FRM))
+                    eod = True
+                    break
+                if vdif.unpack_header(nxt)["second"] != current_sec:
+                    boundary = nxt
+                continue                            # (a duplicate frame of this second: dropped)
+            secs = block[:have].reshape(-1, vdif.VD_FRM)[:, :4].copy().view("<u4")[:, 0] & 0x3FFFFFFF
+            other = np.nonzero(secs != current_sec)[0]
+            if other.size:
+                cut = int(other[0]) * vdif.VD_FRM
+                boundary = block[cut:have].tobytes()
+                # what follows the cut is not this second's: hide it from the device-side frame index
+                block[cut:have].reshape(-1, vdif.VD_FRM)[:, 3] |= 0x80      # VDIF invalid-data bit
+                have = cut
+        self.boundary = boundary
+        if boundary is None:
+            return None, None
+        return have, vdif.unpack_header(boundary[:vdif.VD_FRM])
+
+    def seal(self, block, have):
+        """frames were dropped: whatever an earlier second left in the tail of the block is not data"""
+        if have < self.sec_bytes:
+            block[have:].reshape(-1, vdif.VD_FRM)[:, 3] |= 0x80
+
+    def advance(self):
+        """the second in the block has been handed on: the next one starts with what was read beyond it"""
+        self.current_sec = vdif.unpack_header(self.boundary[:vdif.VD_FRM])["second"]
+        self.carry, self.boundary = self.boundary, None
 
 
 def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None, control_sock=None):
@@ -219,7 +322,6 @@ def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None, control_so
         # supports it -- one copy from the ring instead of three.
         if blocks is None:
             blocks = [_pinned_bytes(sec_bytes) for _ in range(nsets + 1)]
-        readinto = getattr(in_ring, "readinto", None)
         first = in_ring.read(vdif.VD_FRM)
         if len(first) != vdif.VD_FRM:
             log("ERR", "Problem reading first bloody frame!  Bailing.")
@@ -235,7 +337,7 @@ def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None, control_so
         coheimdall_file = cofb_kur if args.rfi_mode else cofb
         write_to_null = args.write_fb == 0
         if args.write_fb == 1:
-            if source_allowed(hdr):
+            if source_allowed(hdr, load_write_allow(log=log)):
                 log("INFO", "Source %s matches target list, recording filterbank data." % hdr.get("NAME", ""))
             else:
                 write_to_null = True
@@ -306,62 +408,20 @@ def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None, control_so
                 out_buf.pop(0)
             prof["write"] += time.time() - t0
 
-        # Frames are placed by their own headers (thread id, frame number: :1017-1034), a second is
-        # closed by the first frame of another second (:1019, :1058) and dispatched only then -- so the last
-        # second of an observation is dropped -- and a frame that never arrives leaves zeros.  The frames of
-        # one second are gathered in a page-locked block in bulk; when frames were dropped the block
-        # swallows the head of the next second, which is carried over, so that the stream re-aligns at
-        # once (the reference loses the dropped frame and nothing else).
-        # Seconds are pipelined over the handle's buffer sets: second k is queued (H2D + kernels) before the
-        # output of second k-1 is collected, so the device works while the host reads and writes.
-        carry = bytes(first)   # frames of the second being assembled that have been read already
+        # Seconds are assembled by a SecondReader (frames placed by their own headers, a second closed by the first
+        # frame of the next one, dropped frames cost only themselves) and pipelined over the handle's buffer sets:
+        # second k is queued (H2D + kernels) before the output of second k-1 is collected, so the device works
+        # while the host reads and writes.
+        reader = SecondReader(in_ring, first, sec_bytes, log)
         queued = 0             # seconds handed to the device
         while True:
             t0 = time.time()
             block = blocks[queued % len(blocks)]
-            have = len(carry)
-            block[:have] = np.frombuffer(carry, np.uint8)
-            carry = b""
-            boundary = None    # bytes (>= one frame) of the next second, already read
-            eod = False
-            while boundary is None and not eod:
-                if have < sec_bytes:
-                    if readinto is not None:
-                        got = readinto(block[have:]) or 0
-                    else:
-                        rest = in_ring.read(sec_bytes - have)
-                        got = len(rest)
-                        block[have:have + got] = np.frombuffer(rest, np.uint8)
-                    if got % vdif.VD_FRM:
-                        log("INFO", "Packet size=%d, expected %d.  Aborting this observation."
-                            % (got % vdif.VD_FRM, vdif.VD_FRM))
-                        got -= got % vdif.VD_FRM
-                        eod = True
-                    elif got < sec_bytes - have:
-                        eod = True
-                    have += got
-                else:
-                    nxt = in_ring.read(vdif.VD_FRM)     # block full and all of this second: the next frame decides
-                    if len(nxt) != vdif.VD_FRM:
-                        if len(nxt):
-                            log("INFO", "Packet size=%d, expected %d.  Aborting this observation." % (len(nxt), vdif.VD_FRM))
-                        eod = True
-                        break
-                    if vdif.unpack_header(nxt)["second"] != current_sec:
-                        boundary = nxt
-                    continue                            # (a duplicate frame of this second: dropped)
-                secs = block[:have].reshape(-1, vdif.VD_FRM)[:, :4].copy().view("<u4")[:, 0] & 0x3FFFFFFF
-                other = np.nonzero(secs != current_sec)[0]
-                if other.size:
-                    cut = int(other[0]) * vdif.VD_FRM
-                    boundary = block[cut:have].tobytes()
-                    # what follows the cut is not this second's: hide it from the device-side frame index
-                    block[cut:have].reshape(-1, vdif.VD_FRM)[:, 3] |= 0x80      # VDIF invalid-data bit
-                    have = cut
+            have, nh = reader.fill(block)
+            current_sec = reader.current_sec
             prof["read"] += time.time() - t0
-            if boundary is None:
+            if have is None:
                 break                                   # end of data: the last (partial or whole) second is dropped
-            nh = vdif.unpack_header(boundary[:vdif.VD_FRM])
             if nh["second"] - current_sec > 1:
                 log("ERR", "Major data skip!  (%d vs. %d; thread = %d) Aborting this observation."
                     % (nh["second"], current_sec, nh["thread"]))
@@ -371,9 +431,7 @@ def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None, control_so
                 log("INFO", "Received CMD_QUIT, indicating data taking is ceasing.  Exiting.")
                 quit_ = True
                 break
-            if have < sec_bytes:
-                # frames were dropped: whatever an earlier second left in the tail of the block is not data
-                block[have:].reshape(-1, vdif.VD_FRM)[:, 3] |= 0x80
+            reader.seal(block, have)
             inject_now = 1 if (args.inject_frb and current_sec % 60 == 0) else 0
             if inject_now:
                 log("INFO", "Injecting an FRB with integrated = %.2f!!!." % float(queued))
@@ -385,8 +443,7 @@ def run(args, in_ring=None, out_ring=None, co_ring=None, handle=None, control_so
             queued += 1
             if queued - st["integrated_sec"] >= nsets:
                 collect(st["integrated_sec"])           # the oldest queued second, while the newest computes
-            current_sec = nh["second"]
-            carry = boundary
+            reader.advance()
         while st["integrated_sec"] < queued:
             collect(st["integrated_sec"])
         integrated_sec, fb_bytes = st["integrated_sec"], st["fb_bytes"]
