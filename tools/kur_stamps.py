@@ -65,6 +65,10 @@ span = (rt1.max() - rt0.min()) / 100.0           # us
 life = (rt1 - rt0) / 100.0
 print("launch span %.1f us; workgroup life mean %.1f us (p10 %.1f, p50 %.1f, p90 %.1f); sum of lives / (256 CUs x span) = %.2f resident per CU"
       % (span, life.mean(), np.percentile(life, 10), np.percentile(life, 50), np.percentile(life, 90), life.sum() / 256.0 / span))
+# the shader clock under this load: s_memtime ticks per microsecond of the 100-MHz clock, per workgroup
+tpu = np.diff(t[:, [0, 5]], axis=1)[:, 0].astype(np.float64) / np.maximum(life, 1e-3)
+print("s_memtime ticks per us of s_memrealtime: mean %.0f (p10 %.0f, p90 %.0f) -> that many MHz if s_memtime counts shader cycles"
+      % (tpu.mean(), np.percentile(tpu, 10), np.percentile(tpu, 90)))
 # residency and workgroup life over the launch, in tenths of the span
 edges = np.linspace(rt0.min(), rt1.max(), 11)
 for i in range(10):

@@ -110,15 +110,22 @@ __device__ __forceinline__ float div_full_weight(float x)
 // done, so that their latency runs under this transform's spectrum step.
 // FIX: code 0 -> 128 on every staging (the input buffer has not been patched by a kurtosis pass); next_pol: the
 // polarisation of the next transform's row.
-template <int ROLE, bool FIX = false>
+// prestaged: the row's (patched) bytes already lie at the start of buf -- the statistic of k_channelize_kur staged
+// them there -- so nothing is staged and no barrier precedes the unpack.
+// DEFER (k_channelize_kur, ROLE 0): the row's flag mask and weight are not known yet when the transform starts (one
+// wave works them out while the others unpack); they are read from `smw` after the FFT, where ROLE 0 first needs
+// them, and what to request next (the same row again for its excised transform, else `after_row` of pol 1) is decided
+// there too.
+template <int ROLE, bool FIX = false, bool DEFER = false>
 __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int tid, int seg, int row, int pol, int ant,
                                                 RowStage &st, unsigned mask, float wrow, size_t prow, int next_row,
-                                                int next_pol = -1)
+                                                int next_pol = -1, bool prestaged = false,
+                                                const unsigned *smw = nullptr, int after_row = -1)
 {
     if (next_pol < 0) next_pol = pol;
     FFT_STAMP(0);
     const unsigned o = (unsigned)(row_byte(a, seg, row, pol, ant) & 15);   // recomputed, not carried from the request
-    {
+    if (!prestaged) {
         // a dropped-frame byte (0) means "no sample" = 0.0 = code 128 (convertarray :23-33), so that the
         // conversion below is one fma per sample pair.  The kurtosis kernel has already patched such codes in
         // the input buffer; only RFI mode 0, which has no kurtosis pass, does it here (four per instruction).
@@ -135,8 +142,8 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
             stage[tid + 512] = st.t2;
             if (last) stage[tid + 768] = st.t3;
         }
+        __syncthreads();
     }
-    __syncthreads();
     FFT_STAMP(1);
     f2 v[25];
     if (tid < 250) {
@@ -163,6 +170,14 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
         }
     };
     fft6250(v, buf, (const f2 *)a.tw2, (const f2 *)a.tw3, tid, load_tq);
+    if (DEFER) {
+        // (written by wave 0 before the barrier in front of pass 1)
+        mask = __builtin_amdgcn_readfirstlane(smw[0]);
+        wrow = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(smw[1]));
+        const bool again = (a.rfi_mode == 1 || (a.rfi_mode == 2 && mask != 0)) && mask != 0x1ffffffu;
+        next_row = again ? row : after_row;
+        next_pol = again ? pol : 1;
+    }
 #ifndef FFT_LEAN
     if (next_row >= 0) stage_request(a, tid, seg, next_row, next_pol, ant, st);
 #endif
@@ -339,6 +354,7 @@ extern "C" int pb_internal_kur_stamps(unsigned long long *out)
 __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
 {
     __shared__ __attribute__((aligned(16))) f2 buf[M_HALF];
+    __shared__ unsigned smw[2];     // the row's flag mask and weight bits (outside buf: the transforms overwrite that)
 #ifdef KUR_STAMP
     __shared__ unsigned long long kts[8];
 #endif
@@ -352,12 +368,12 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
     const int row = blockIdx.x, seg = blockIdx.y, ant = blockIdx.z;
     const int grow = seg * a.R + row;
 
-    // both rows' bytes: pol 0 stays in registers for the first transform, both go to LDS for the statistics
+    // both rows' bytes go to LDS, patched for code 0, for the statistics; pol 0's stay where its first transform
+    // expects them (the start of buf), so that transform stages nothing
     RowStage st;
     unsigned off0, off1;
     uint4 *sraw0 = (uint4 *)buf, *sraw1 = (uint4 *)buf + 784;     // 2 x 12 544 B
-    float *s2 = (float *)((uint4 *)buf + 2 * 784), *s4 = s2 + 50, *sdag = s4 + 50;
-    unsigned *smw = (unsigned *)(sdag + 50);                       // [0] mask, [1] weight bits
+    float *s2 = (float *)((uint4 *)buf + 2 * 784), *s4 = s2 + 50;
     {
         RowStage sb;
         stage_request(a, tid, seg, row, 0, ant, st);
@@ -450,19 +466,23 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
     }
     __syncthreads();
     KSTAMP(2);
-    if (tid < 50) {
-        const float p = s2[tid] / PB_NKURTO;
-        const float k = s4[tid] / PB_NKURTO / (p * p);
-        sdag[tid] = dag_flag(k, *a.dag) ? 9.0f : 0.0f;     // (the flag only: no cube root, kurtosis_dev.h)
-    }
-    __syncthreads();
-    KSTAMP(3);
-    if (tid < 25) {
-        const float dmax = fmaxf(sdag[tid], sdag[25 + tid]);
-        const bool bad = dmax > 3.0f;  // DAG_THRESH
-        a.flags[(size_t)ant * a.flags_ant_stride + (size_t)grow * PB_BLK_PER_FFT + tid] = bad ? 1 : 0;
-        const uint32_t m = (uint32_t)__ballot(bad);
-        if (tid == 0) {
+    // The flags are the business of ONE wave: lanes 0..49 decide their block's flag (no cube root, kurtosis_dev.h), a
+    // ballot brings the two pols together (bit b of the mask = block b flagged in pol 0 or pol 1: compute_dagostino's
+    // max over pols, :109-134), lane 0 books the weight.  The other waves go straight on to unpacking pol 0, whose
+    // bytes are where the transform expects them; the mask and the weight are first needed after that transform's FFT
+    // (RFI mode 2), and they reach the other waves through `smw` across the barrier that precedes pass 1 -- which
+    // also keeps pass 1 from overwriting the moments before this wave has read them.
+    if (wave == 0) {
+        bool f = false;
+        if (lane < 50) {
+            const float p = s2[lane] / PB_NKURTO;
+            const float k = s4[lane] / PB_NKURTO / (p * p);
+            f = dag_flag(k, *a.dag);
+        }
+        const unsigned long long b = __ballot(f);
+        const uint32_t m = (uint32_t)((b | (b >> 25)) & 0x1ffffffull);
+        if (lane < 25) a.flags[(size_t)ant * a.flags_ant_stride + (size_t)grow * PB_BLK_PER_FFT + lane] = (m >> lane) & 1u;
+        if (lane == 0) {
             // kur_weights after apply_kurtosis (:292): one 500/12500 per unflagged block, summed left to right
             const float inc = (float)PB_NKURTO / PB_NFFT;
             float w = 0.f;
@@ -473,27 +493,32 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
             smw[1] = __builtin_bit_cast(unsigned, w);
         }
     }
-    __syncthreads();
-    const unsigned mask = __builtin_amdgcn_readfirstlane(smw[0]);
-    const float wrow = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(smw[1]));
-    __syncthreads();        // mask and weight are in registers: the transforms may overwrite buf
+    KSTAMP(3);
+    unsigned mask = 0;
+    float wrow = 0.f;
+    if (a.rfi_mode == 1) {
+        // the excised transform zeroes flagged blocks while it unpacks: it needs the mask first
+        __syncthreads();
+        mask = __builtin_amdgcn_readfirstlane(smw[0]);
+        wrow = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(smw[1]));
+    }
     KSTAMP(4);
 
-    const bool all_bad = mask == 0x1ffffffu;
-    const bool second = a.rfi_mode == 1 || (a.rfi_mode == 2 && mask != 0);
 #pragma unroll 1
     for (int pol = 0; pol < 2; ++pol) {
         const size_t prow = (size_t)ant * a.p_ant_stride + (((size_t)seg * 2 + pol) * a.R + row) * PB_NCHANOUT;
         const int after_row = pol == 0 ? row : -1;         // what follows this pol's transforms: pol 1 of the same row
         if (pol) __syncthreads();   // the previous transform has finished reading buf
         if (a.rfi_mode != 1) {
-            // what is requested while this transform is in its spectrum step: the same row again for its excised
-            // transform, else pol 1's row
-            const bool again = second && !all_bad;
-            channelize_pass<0, true>(a, buf, tid, seg, row, pol, ant, st, mask, wrow, prow, again ? row : after_row,
-                                     again ? pol : 1);
-            if (!second) continue;
+            // what is requested while this transform is in its spectrum step -- the same row again for its excised
+            // transform, else pol 1's row -- is decided inside, once the mask is known
+            channelize_pass<0, true, true>(a, buf, tid, seg, row, pol, ant, st, 0u, 0.f, prow, -1, 1, pol == 0, smw, after_row);
+            mask = __builtin_amdgcn_readfirstlane(smw[0]);
+            wrow = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(smw[1]));
         }
+        const bool all_bad = mask == 0x1ffffffu;
+        const bool second = a.rfi_mode == 1 || (a.rfi_mode == 2 && mask != 0);
+        if (!second) continue;
         if (all_bad) {
             for (int c = tid; c < PB_NCHANOUT; c += 256) a.Pkur[prow + c] = __builtin_inff();
             if (a.rfi_mode == 1 && after_row >= 0) stage_request(a, tid, seg, after_row, 1, ant, st);
@@ -503,7 +528,9 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
             __syncthreads();   // the raw pass has finished reading buf
             asm volatile("" : "+v"(tid));   // no sharing of tid-derived addresses across the two passes
         }
-        channelize_pass<1, true>(a, buf, tid, seg, row, pol, ant, st, mask, wrow, prow, after_row, 1);
+        // (RFI mode 1, pol 0: the bytes the statistic staged are still where this transform expects them)
+        channelize_pass<1, true>(a, buf, tid, seg, row, pol, ant, st, mask, wrow, prow, after_row, 1,
+                                 a.rfi_mode == 1 && pol == 0);
     }
 #ifdef KUR_STAMP
     if (threadIdx.x == 0 && blockIdx.z == 0) {
