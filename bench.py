@@ -177,6 +177,133 @@ def measured_traffic(stage, args, taps, A=1):
     return best
 
 
+def measured_valu(args, taps, A=1):
+    """Vector instructions per launch of the step's kernels from the committed rocprofv3 PMC summary of THIS build
+    (tools/profile_counters.sh + tools/summarise_counters.py: SQ_INSTS_VALU per kernel, kernel-source hash recorded).
+    None when there is no summary of these kernels / this configuration."""
+    import glob
+    if args.backend != "lds" or args.rfi_mode != 2 or args.seg_per_step != 10 or A != 1 or args.rfi_frac:
+        return None
+    sha = kernel_source_hash()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_issue_counters.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("kernel_source_sha16") != sha or d.get("taps", 1) != taps:
+            continue
+        out = {k: int(v["SQ_INSTS_VALU"]) for k, v in d.get("kernels", {}).items() if "SQ_INSTS_VALU" in v and k != "k_copy_out"}
+        if out:
+            return {"per_launch": out, "packed_share": d.get("packed_share", {}), "source": os.path.basename(f)}
+    return None
+
+
+# cycles a SIMD needs per wave64 vector instruction with three or more waves to choose from (tools/ubench_valu.hip,
+# profiles/r02_ubench_valu.txt: 1.90 for v_fma / v_add / v_mul_f32, 2.82 for the packed-f32 forms)
+VALU_CYC_SCALAR, VALU_CYC_PACKED, N_SIMD = 1.90, 2.82, 1024
+
+
+def valu_record(args, taps, ms_per_step, gfx_mhz):
+    """The vector pipes' share of the step: instructions of the step's kernels x the measured cycles per instruction
+    / (1024 SIMDs x the step's cycles at the clock the chip held).  The path is a streaming FFT: HBM is the
+    roofline the metric names, this is the other ceiling beside it."""
+    mv = measured_valu(args, taps)
+    if mv is None:
+        return None
+    cyc = 0.0
+    for k, n in mv["per_launch"].items():
+        pk = float(mv["packed_share"].get(k, 0.5))
+        cyc += n * (pk * VALU_CYC_PACKED + (1.0 - pk) * VALU_CYC_SCALAR)
+    mhz = gfx_mhz or 2400.0
+    step_cycles = ms_per_step * 1e-3 * mhz * 1e6
+    return {"insts_per_step": int(sum(mv["per_launch"].values())), "per_kernel": mv["per_launch"],
+            "packed_share": mv["packed_share"], "cycles_per_inst": {"scalar_f32": VALU_CYC_SCALAR, "packed_f32": VALU_CYC_PACKED},
+            "simd_cycles_per_step": round(cyc / N_SIMD), "step_cycles": round(step_cycles), "gfx_mhz": round(mhz),
+            "frac": round(cyc / N_SIMD / step_cycles, 4), "source": mv["source"]}
+
+
+def power_record(torch, lp, args, dev, local, taps, seconds=2.0):
+    """What the package does while the pipeline runs: socket power against its cap, the XCDs' clocks and the share of
+    the time the firmware spent throttling for package power (amdsmi GPU metrics, ppt_residency_acc against
+    accumulation_counter), over `seconds` of untimed steps.  Reported because it is the bound the kernels run
+    into: both pipes are under half busy, HBM at a third, and the chip sits at its power cap."""
+    try:
+        import amdsmi
+        import threading
+        amdsmi.amdsmi_init()
+        g = amdsmi.amdsmi_get_processor_handles()[local]
+    except Exception as e:
+        return {"error": "amdsmi: %s" % e}
+    S = args.seg_per_step
+    h = lp.PbHandle(device=local, nant=1, nbit=args.nbit, npol=1, rfi_mode=args.rfi_mode, rows_per_seg=ROWS, max_seg=S,
+                    nsets=args.nsets, taps=taps, fft_backend=lp.FFT_LDS if args.backend == "lds" else lp.FFT_HIPFFT)
+    n = h.seg_samples
+    sec = synth_second(torch, dev, 42, n, S, rfi_frac=args.rfi_frac)
+    torch.cuda.synchronize()
+    for st in range(args.nsets):
+        h.select_set(st)
+        for s in range(S):
+            h.submit_planar_dev(0, s, sec[s][0].data_ptr(), sec[s][1].data_ptr(), n)
+    h.sync()
+    del sec
+    samples, stop = [], [False]
+
+    def sampler():
+        while not stop[0]:
+            try:
+                m = amdsmi.amdsmi_get_gpu_metrics_info(g)
+                clk = [c for c in m.get("current_gfxclks", []) if isinstance(c, (int, float)) and c > 0]
+                samples.append((m.get("current_socket_power"), sum(clk) / len(clk) if clk else None, m.get("average_umc_activity")))
+            except Exception:
+                pass
+            time.sleep(0.05)
+
+    def steps(dur):
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < dur:
+            h.select_set(k % args.nsets)
+            h.process(S)
+            if k >= args.nsets - 1:
+                h.select_set((k - args.nsets + 1) % args.nsets)
+                h.fetch_view(0, 1 if args.rfi_mode else 0, S)
+            k += 1
+        h.sync()
+        return k, time.perf_counter() - t0
+
+    steps(0.3)                                    # (clock ramp)
+    try:
+        cap = amdsmi.amdsmi_get_power_cap_info(g).get("power_cap", 0) / 1e6
+        m0 = amdsmi.amdsmi_get_gpu_metrics_info(g)
+        th = threading.Thread(target=sampler, daemon=True)
+        th.start()
+        k, dt = steps(seconds)
+        stop[0] = True
+        th.join(timeout=5)
+        m1 = amdsmi.amdsmi_get_gpu_metrics_info(g)
+    except Exception as e:
+        h.close()
+        return {"error": "amdsmi: %s" % e}
+    h.close()
+    pw = [s[0] for s in samples if isinstance(s[0], (int, float))]
+    ck = [s[1] for s in samples if s[1]]
+    um = [s[2] for s in samples if isinstance(s[2], (int, float))]
+
+    def delta(key):
+        a, b = m0.get(key), m1.get(key)
+        return (b - a) if isinstance(a, (int, float)) and isinstance(b, (int, float)) else None
+
+    acc, ppt = delta("accumulation_counter"), delta("ppt_residency_acc")
+    return {"socket_w": round(sum(pw) / len(pw), 1) if pw else None, "cap_w": cap or None,
+            "frac_of_cap": round(sum(pw) / len(pw) / cap, 4) if pw and cap else None,
+            "gfx_mhz": round(sum(ck) / len(ck)) if ck else None, "gfx_mhz_max": 2400,
+            "power_throttle_residency": round(ppt / acc, 4) if acc and ppt is not None else None,
+            "thermal_throttle_residency": round((delta("socket_thm_residency_acc") or 0) / acc, 4) if acc else None,
+            "hbm_controller_activity_pct": round(sum(um) / len(um), 1) if um else None,
+            "ms_per_step_while_sampled": round(dt / k * 1e3, 4), "seconds": seconds, "samples": len(pw),
+            "note": "amdsmi GPU metrics while the pipeline runs untimed: socket power against the package cap, mean of the "
+                    "XCDs' current clocks, ppt (package power) throttle residency = d ppt_residency_acc / d accumulation_counter"}
+
+
 def algorithmic_bytes(args, h, n, world, taps):
     """compulsory HBM bytes per antenna-segment of each kernel"""
     nstreams = 2 if args.rfi_mode == 2 else 1
@@ -479,6 +606,7 @@ def build_parser():
                          "without it a run with fewer GPUs than ranks fails")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the ranks --gpus N starts (0: pick one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="skip the 2-s power / clock / throttle sample (roofline.power)")
     ap.add_argument("--no-extras", action="store_true", help="skip the taps4 / ingest / search / configs3 sub-records")
     ap.add_argument("--coadd-selftest", action="store_true",
                     help="N = 1 only: print the step with the incoherent-sum leg of the N > 1 path switched on "
@@ -646,6 +774,16 @@ def main():
                 out["roofline"]["alone"] = alone_record(torch, lp, args, dev, local, args.taps)
             except Exception as e:
                 out["roofline"]["alone"] = {"error": str(e)}
+            if not args.no_power:
+                try:
+                    out["roofline"]["power"] = power_record(torch, lp, args, dev, local, args.taps)
+                except Exception as e:
+                    out["roofline"]["power"] = {"error": str(e)}
+            try:
+                pw = out["roofline"].get("power") or {}
+                out["roofline"]["valu"] = valu_record(args, args.taps, r["ms_per_step"], pw.get("gfx_mhz"))
+            except Exception as e:
+                out["roofline"]["valu"] = {"error": str(e)}
         if world == 1 and not args.no_extras and args.taps == 1 and A == 1:
             nsub = max(20, 2 * args.steps // 3)      # (short runs time the pipeline's fill and drain)
             t4 = run_chain(torch, dist, lp, args, dev, local, rank, world, 4, nsub, min(args.warmup, 5))

@@ -73,3 +73,32 @@ def test_a_gulp_without_candidates_is_two_lines():
 def test_coincidencer_spec():
     assert cand.parse_coincidencer("vlite-nrl:27555") == ("vlite-nrl", 27555)
     assert cand.parse_coincidencer("vlite-nrl") == ("vlite-nrl", cand.HEIMDALL_PORT)
+
+
+def test_overlap_rule_and_point_grouping():
+    """search.overlap restates the reference coincidencer's test (src/candidate.py:49-65): fractional DM difference,
+    width ratio <= 3, overlapping [i0, i1); search.group_points clusters the points of one series by time and DM
+    (strongest first, deterministic under ties) and applies the width test only on request."""
+    import numpy as np
+    search = importlib.import_module("vlite-fast_amd.search")
+    a = dict(dm=100.0, i0=1000, i1=1008)
+    assert search.overlap(a, dict(dm=105.0, i0=1004, i1=1012))
+    assert not search.overlap(a, dict(dm=112.0, i0=1004, i1=1012))               # |100/112 - 1| = 0.107 > 0.1
+    assert search.overlap(dict(dm=112.0, i0=1004, i1=1012), dict(dm=102.0, i0=1000, i1=1008))   # relative to the OTHER's DM
+    assert not search.overlap(a, dict(dm=100.0, i0=1008, i1=1016))               # [i0, i1) touch, do not overlap
+    assert search.overlap(a, dict(dm=100.0, i0=1007, i1=1031))                   # widths 8 and 24: ratio 3 passes
+    assert not search.overlap(a, dict(dm=100.0, i0=1007, i1=1032))               # 25 / 8 > 3
+    assert search.overlap(a, dict(dm=100.0, i0=1007, i1=1032), delta_w=None)
+    # one pulse seen at widths 1..64 around sample 500 at DM index 10, a second event far away in DM
+    dms = np.arange(40) * 10.0
+    idm = np.array([10, 10, 10, 10, 11, 30, 30])
+    it = np.array([500, 499, 497, 480, 500, 505, 505])
+    w = np.array([4, 8, 16, 64, 4, 2, 4])
+    sn = np.array([20.0, 18.0, 15.0, 9.0, 12.0, 8.0, 8.0])
+    c = search.group_points(idm, it, sn, w, dms, 7.8125e-4)
+    assert [x["dmi"] for x in c] == [10, 30] and c[0]["ngiant"] == 5 and c[0]["i0"] == 480 and c[0]["i1"] == 544
+    assert c[0]["tfilt"] == 2 and c[1]["ngiant"] == 2 and c[1]["tfilt"] == 1     # the tie at DM 30: the narrower first
+    c3 = search.group_points(idm, it, sn, w, dms, 7.8125e-4, delta_w=3)
+    assert len(c3) == 4 and c3[0]["ngiant"] == 3                                 # widths 16 and 64 split off
+    pk = dict(dmi=idm[::-1].copy(), t=it[::-1].copy(), snr=sn[::-1].copy(), width_log2=np.log2(w[::-1]).astype(np.uint8))
+    assert search.candidates_from_peaks(pk, dms, 7.8125e-4) == c                 # arrival order does not matter

@@ -147,53 +147,64 @@ class Searcher(object):
         return dict(snr=snr, width_log2=wid, stats=stats, series=series, tout=tout)
 
 
-def find_candidates(snr, width_log2, dms, tsamp, threshold=6.0, dm_tol=0.1, sample0=0):
-    """Group above-threshold (dm, t) samples into candidates: strongest first, a candidate absorbs
-    every sample that overlaps it in time and lies within dm_tol (fractional) in DM -- the overlap
-    rule of the reference's coincidencer (src/candidate.py:49-65).  Returns a list of dicts with
-    heimdall's columns."""
-    idm, it = np.nonzero(snr >= threshold)
-    if idm.size == 0:
-        return []
-    s = snr[idm, it]
-    w = (1 << width_log2[idm, it].astype(np.int64))
-    order = np.argsort(-s)
-    idm, it, s, w = idm[order], it[order], s[order], w[order]
-    taken = np.zeros(idm.size, bool)
-    cands = []
-    for k in range(idm.size):
-        if taken[k]:
-            continue
-        i0, i1, dm = it[k], it[k] + w[k], dms[idm[k]]
-        near = (~taken) & (it < i1) & (it + w > i0) & (np.abs(dms[idm] - dm) <= dm_tol * max(dm, 1.0) + 1e-9)
-        taken |= near
-        cands.append(dict(snr=float(s[k]), peak_idx=int(sample0 + it[k]), peak_time=float((sample0 + it[k]) * tsamp),
-                          tfilt=int(np.log2(w[k])), dmi=int(idm[k]), dm=float(dm), ngiant=int(near.sum()),
-                          i0=int(sample0 + it[near].min()), i1=int(sample0 + (it[near] + w[near]).max())))
-    return cands
+def overlap(c, o, delta_dm=0.1, delta_w=3):
+    """The reference coincidencer's test for "the same event" between two candidates, src/candidate.py:49-65:
+    DMs within delta_dm (fractional, relative to the other's DM), widths (i1 - i0) within a factor delta_w, and the
+    sample ranges [i0, i1) overlapping.  c, o: dicts with dm, i0, i1.  delta_w None: no width test."""
+    if o["dm"] == 0 or abs(c["dm"] / o["dm"] - 1) > delta_dm:
+        if not (o["dm"] == 0 and c["dm"] == 0):
+            return False
+    if delta_w is not None:
+        w1, w2 = float(c["i1"] - c["i0"]), float(o["i1"] - o["i0"])
+        if min(w1, w2) <= 0 or max(w1, w2) / min(w1, w2) > delta_w:
+            return False
+    if c["i0"] < o["i0"]:
+        return o["i0"] < c["i1"]
+    return c["i0"] < o["i1"]
 
 
-def candidates_from_peaks(pk, dms, tsamp, dm_tol=0.1, sample0=0):
-    """find_candidates on a peak list (Searcher.peaks) instead of full S/N planes"""
-    idm, it, sn, w = pk["dmi"].astype(np.int64), pk["t"].astype(np.int64), pk["snr"], (1 << pk["width_log2"].astype(np.int64))
+def group_points(idm, it, sn, w, dms, tsamp, dm_tol=0.1, delta_w=None, sample0=0):
+    """Above-threshold (DM index, sample, S/N, boxcar width) points of ONE beam's search -> candidates: strongest
+    first, a candidate absorbs every point that overlaps it in time and lies within dm_tol (fractional) of its DM.
+    This clustering is this framework's own (heimdall's, which the reference runs at this place, is third-party and
+    absent: unpinned).  It uses the time and DM tests of the reference's cross-beam coincidencer (src/candidate.py:
+    53-54, 64-66) but by default NOT its width-ratio test (:57-63, delta_w = 3): the points of one series are boxcar
+    trials of the same samples, a pulse shows up at every width from 1 to 64, and splitting them by width would
+    report one pulse several times.  delta_w (e.g. 3) applies that test as well, for like-for-like experiments.
+    Ties in S/N are broken by (DM index, sample, width): the GPU appends points in arrival order, which differs from run
+    to run, and the grouping depends on the order.  Returns dicts with heimdall's nine columns."""
+    idm, it, w = np.asarray(idm, np.int64), np.asarray(it, np.int64), np.asarray(w, np.int64)
+    sn = np.asarray(sn)
     if idm.size == 0:
         return []
-    # strongest first; ties by (DM index, sample): the GPU appends points in arrival order, which differs from run
-    # to run, and the grouping below depends on the order
-    order = np.lexsort((it, idm, -sn.astype(np.float64)))
+    order = np.lexsort((w, it, idm, -sn.astype(np.float64)))
     idm, it, sn, w = idm[order], it[order], sn[order], w[order]
+    pdm = np.asarray(dms)[idm]
     taken = np.zeros(idm.size, bool)
     cands = []
     for k in range(idm.size):
         if taken[k]:
             continue
-        i0, i1, dm = it[k], it[k] + w[k], dms[idm[k]]
-        near = (~taken) & (it < i1) & (it + w > i0) & (np.abs(dms[idm] - dm) <= dm_tol * max(dm, 1.0) + 1e-9)
+        i0, i1, dm = it[k], it[k] + w[k], pdm[k]
+        near = (~taken) & (it < i1) & (it + w > i0) & (np.abs(pdm - dm) <= dm_tol * max(dm, 1.0) + 1e-9)
+        if delta_w is not None:
+            near &= (np.maximum(w, w[k]) <= delta_w * np.minimum(w, w[k]))
         taken |= near
         cands.append(dict(snr=float(sn[k]), peak_idx=int(sample0 + it[k]), peak_time=float((sample0 + it[k]) * tsamp),
                           tfilt=int(np.log2(w[k])), dmi=int(idm[k]), dm=float(dm), ngiant=int(near.sum()),
                           i0=int(sample0 + it[near].min()), i1=int(sample0 + (it[near] + w[near]).max())))
     return cands
+
+
+def find_candidates(snr, width_log2, dms, tsamp, threshold=6.0, dm_tol=0.1, sample0=0, delta_w=None):
+    """group_points on full S/N planes (Searcher.run): every (DM, sample) at or above the threshold"""
+    idm, it = np.nonzero(snr >= threshold)
+    return group_points(idm, it, snr[idm, it], 1 << width_log2[idm, it].astype(np.int64), dms, tsamp, dm_tol, delta_w, sample0)
+
+
+def candidates_from_peaks(pk, dms, tsamp, dm_tol=0.1, sample0=0, delta_w=None):
+    """group_points on a peak list (Searcher.peaks) instead of full S/N planes"""
+    return group_points(pk["dmi"], pk["t"], pk["snr"], 1 << pk["width_log2"].astype(np.int64), dms, tsamp, dm_tol, delta_w, sample0)
 
 
 class GulpSearch(object):
