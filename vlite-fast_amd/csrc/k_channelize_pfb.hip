@@ -238,11 +238,11 @@ __device__ __forceinline__ void pfb_pass(const PfbArgs &a, uint8_t *lds, int tid
             const f2 sq = X * X;
             pw[q] = sq.x + sq.y;
         }
-        if (role == 0) store_plane4(P0 + c4, pw[0], pw[1], pw[2], pw[3]);
+        if (role == 0) store_plane4(P0, c4, pw[0], pw[1], pw[2], pw[3]);
         if (role == 1 || (also_kur && w != 1.0f))
-            store_plane4((role == 1 ? P0 : P1) + c4, pw[0] / w, pw[1] / w, pw[2] / w, pw[3] / w);
+            store_plane4(role == 1 ? P0 : P1, c4, pw[0] / w, pw[1] / w, pw[2] / w, pw[3] / w);
         else if (also_kur)      // x / 1 = x: no division for a row whose window is complete and unflagged
-            store_plane4(P1 + c4, pw[0], pw[1], pw[2], pw[3]);
+            store_plane4(P1, c4, pw[0], pw[1], pw[2], pw[3]);
     }
 }
 

@@ -106,7 +106,7 @@ hipError_t launch_copy_out(uint8_t *host_pinned, const uint8_t *dev, size_t nbyt
     return hipGetLastError();
 }
 
-hipError_t launch_detect(pb_handle *h, int nseg, int)
+hipError_t launch_detect(pb_handle *h, int nseg, int, bool fine_grained)
 {
     if (h->cfg.fft_backend == PB_FFT_HIPFFT) {
         // complex spectra -> power planes of the segments just transformed (all antennas at once when
@@ -126,7 +126,7 @@ hipError_t launch_detect(pb_handle *h, int nseg, int)
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    return launch_detect_pow(h, nseg);
+    return launch_detect_pow(h, nseg, fine_grained);
 }
 
 // ---- incoherent coadd helpers (pb_coadd_local / pb_coadd_finish) ----

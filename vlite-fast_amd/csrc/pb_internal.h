@@ -81,6 +81,11 @@ struct pb_handle {
     float frb_width, frb_amp;   // inject_frb parameters (rows, amplitude factor)
     // --- pipeline slots: the d_* buffers above (except d_bp, d_vdif, tables) exist once per
     // set; the members above always alias the SELECTED set (pb_select_set)
+    // Row-ready counters of the selected set: [A][S][R / chunk_rows] uint32, one per detect chunk.  The channeliser
+    // that flags its own rows adds 1 per finished row (both pols, both planes written through to the fabric); detect,
+    // launched beside that channeliser instead of after it, takes a chunk only once its counter has reached
+    // chunk_rows x (number of batches the set's segment has seen): pb_handle::ready_epoch.  Monotonic: never reset.
+    uint32_t *d_ready;
     uint8_t *h_codes;      // pinned mirror of d_codes, filled asynchronously after detect
     hipEvent_t ev_chan;    // kernels of this set done (its D2H may start)
     hipEvent_t ev_det;     // D2H of this set done (set may be refilled / fetched)
@@ -90,9 +95,13 @@ struct pb_handle {
         uint8_t *d_in, *d_flags, *d_codes, *h_codes;
         float *d_wrow, *d_stats, *d_fraw, *d_fkur, *d_Praw, *d_Pkur, *d_ave, *d_coadd_target;
         float2 *d_Xraw, *d_Xkur;
+        uint32_t *d_ready;
         hipEvent_t ev_chan, ev_det, ev_cl;
         int processed;
     };
+    std::vector<std::vector<uint32_t>> ready_epoch;   // [set][seg] batches that segment slot of the set has seen
+    int chunk_rows;                                    // detect's chunk: 32 rows, 8 when R is not a multiple of 32
+    uint32_t *d_fg_error;                              // a detect workgroup gave up waiting for a row (must stay 0)
     std::vector<BufSet> sets;
     int cur_set;
     hipStream_t s_det;     // detect of the previous batch (pipelined mode); copy-out in the single-set mode
@@ -123,6 +132,12 @@ struct pb_handle {
 // front of it: in-library FFT, rectangular window, an RFI mode that flags, no statistics kept.  PB_FUSE_KURTOSIS=0
 // keeps the two kernels (timing experiments).
 bool pb_fused_kurtosis(const pb_handle *h);
+// detect runs beside the channeliser of its OWN batch, chunk by chunk behind it (row-ready counters), instead of
+// after it: the fused in-library-FFT path with two or more buffer sets, one antenna per handle, at most 16 segments
+// per call.  An experiment that is bit-exact but did not pay: only with PB_FINE_GRAINED=1 (default: the event between
+// the two kernels).
+bool pb_fine_grained(const pb_handle *h);
+#define PB_FG_MAXSEG 16
 
 // row flag masks (bit r = kurtosis block r of the row is flagged), written by k_kurtosis_row behind the weights
 static inline uint32_t *pb_rowmask(pb_handle *h) { return (uint32_t *)(h->d_wrow + (size_t)h->A * h->S * h->R); }
@@ -133,8 +148,8 @@ hipError_t launch_deframe(pb_handle *h, int ant, int seg0, size_t nframes_per_th
 hipError_t launch_dag_scan(pb_handle *h, const DagConsts &c, uint32_t bits0, int n, uint8_t *d_out);
 hipError_t launch_dag_check(pb_handle *h, uint32_t bits_lo, uint64_t n, unsigned long long *d_mismatches);
 hipError_t launch_inject_c64(pb_handle *h, int nseg, int inject_now);
-hipError_t launch_detect(pb_handle *h, int nseg, int inject_now);
-hipError_t launch_detect_pow(pb_handle *h, int nseg);
+hipError_t launch_detect(pb_handle *h, int nseg, int inject_now, bool fine_grained = false);
+hipError_t launch_detect_pow(pb_handle *h, int nseg, bool fine_grained = false);
 // device -> pinned host copy done by a kernel (see k_detect.hip: hipMemcpyAsync blocks the host now and then)
 hipError_t launch_copy_out(uint8_t *host_pinned, const uint8_t *dev, size_t nbytes, hipStream_t st);
 hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now);
