@@ -8,7 +8,7 @@ src=$1; shift
 make -s
 mkdir -p ../../build/variants
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -I../../include -I. -w"
-others=$(ls *.o | grep -v "^${src%.hip}.o$")
+others=$(ls *.o | grep -v "\.fg\.o$" | grep -v "^${src%.hip}.o$")
 for spec in "$@"; do
   name=${spec%%=*}; defs=${spec#*=}
   /opt/rocm/bin/hipcc $FLAGS $defs -c -o ../../build/variants/${src%.hip}_$name.o $src

@@ -334,8 +334,12 @@ __device__ __forceinline__ void read_z_pairs(const f2 *buf, int k0, f2 (&za)[4],
 // Power-plane stores.  PB_NT_STORES: as streaming (non-temporal) stores -- 671 MB per launch of planes that
 // nobody on this die reads again pass through a 4-MB L2 and push out the rows' bytes that a workgroup requests a
 // second time 20 us later.
-#ifndef PB_NT_STORES
-#define PB_NT_STORES 2     // 0 ordinary, 1 non-temporal, 2 written through to the fabric at system scope (store_plane4)
+#ifndef PB_NT_STORES      // 0 ordinary, 1 non-temporal, 2 written through to the fabric at system scope (store_plane4)
+#if PB_FG
+#define PB_NT_STORES 2
+#else
+#define PB_NT_STORES 1
+#endif
 #endif
 #ifndef PB_WT_AUX
 #define PB_WT_AUX 19        // cache policy of the write-through form: 1 = sc0, 2 = nt, 16 = sc1 (sc0 sc1 = system scope)

@@ -490,9 +490,14 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
             const float inc = (float)PB_NKURTO / PB_NFFT;
             float w = 0.f;
             for (int k = PB_BLK_PER_FFT - __popc(m); k > 0; --k) w = w + inc;
+#if PB_FG
             // (system-scope stores: detect may read the weight while this kernel is still running)
             __hip_atomic_store(a.wrow_out + (size_t)ant * a.wrow_ant_stride + grow, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(a.rowmask_out + (size_t)ant * a.wrow_ant_stride + grow, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+            a.wrow_out[(size_t)ant * a.wrow_ant_stride + grow] = w;
+            a.rowmask_out[(size_t)ant * a.wrow_ant_stride + grow] = m;
+#endif
             smw[0] = m;
             smw[1] = __builtin_bit_cast(unsigned, w);
         }
@@ -524,8 +529,12 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
         const bool second = a.rfi_mode == 1 || (a.rfi_mode == 2 && mask != 0);
         if (!second) continue;
         if (all_bad) {
+#if !PB_FG
+            for (int c = tid; c < PB_NCHANOUT; c += 256) a.Pkur[prow + c] = __builtin_inff();
+#else
             const float inf = __builtin_inff();
             for (int c = tid * 4; c < PB_NCHANOUT; c += 1024) store_plane4(a.Pkur + prow, c, inf, inf, inf, inf);
+#endif
             if (a.rfi_mode == 1 && after_row >= 0) stage_request(a, tid, seg, after_row, 1, ant, st);
             continue;
         }
@@ -537,6 +546,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
         channelize_pass<1, true>(a, buf, tid, seg, row, pol, ant, st, mask, wrow, prow, after_row, 1,
                                  a.rfi_mode == 1 && pol == 0);
     }
+#if PB_FG     // (only the fine-grained build carries this: the extra live values cost k_channelize_kur twenty spilled registers)
     if (a.ready) {
         // This row is complete: every thread's plane stores (written through to the fabric, PB_NT_STORES 2) and wave
         // 0's weight / mask have left for memory once vmcnt has drained; then one thread tells detect, which runs
@@ -549,6 +559,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
             __hip_atomic_fetch_add(a.ready + ((size_t)ant * a.S + seg) * (a.R / a.chunk_rows) + row / a.chunk_rows, 1u,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#endif
 #ifdef KUR_STAMP
     if (threadIdx.x == 0 && blockIdx.z == 0) {
         const unsigned wg = blockIdx.x + gridDim.x * blockIdx.y;

@@ -18,6 +18,9 @@
 #ifndef PB_NT_STORES
 #define PB_NT_STORES 0
 #endif
+#if PB_NT_STORES == 3       // (variant builds: the header's default)
+#undef PB_NT_STORES
+#endif
 #include "fft_lds.h"
 
 #ifndef PFB_DBG

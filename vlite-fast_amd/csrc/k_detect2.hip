@@ -67,10 +67,14 @@ struct Detect2Args {
 #endif
 
 #ifndef D2_LOAD_AUX
-// cache-policy bits of the plane loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).  System scope: the planes are read once,
-// and they may have been written (through, fft_lds.h) by a kernel that is still running on another die -- a line this
-// die's L2 kept from the buffer's previous use must not answer.  Costs nothing (profiles/r04_notes.md).
+// cache-policy bits of the plane loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).  The fine-grained build reads at system
+// scope: the planes may have been written (through, fft_lds.h) by a kernel that is still running on another die -- a
+// line this die's L2 kept from the buffer's previous use must not answer.  Costs nothing (profiles/r04_notes.md).
+#if PB_FG
 #define D2_LOAD_AUX 17
+#else
+#define D2_LOAD_AUX 0
+#endif
 #endif
 #ifndef D2_PRIO_A
 #define D2_PRIO_A 3                // wave priority of the recurrence wave

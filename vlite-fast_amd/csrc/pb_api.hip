@@ -48,11 +48,11 @@ bool pb_fused_kurtosis(const pb_handle *h)
 
 bool pb_fine_grained(const pb_handle *h)
 {
-    // Off unless PB_FINE_GRAINED=1: bit-exact (the pipelined parity tests pass with it), but measured slower -- 0.647 -
-    // 0.655 against 0.632 ms per step in 40-step regions on the same box (profiles/r04_notes.md): detect's workgroups of
-    // batch k + 1 can only start when batch k's have all left, by then the channeliser has taken their places, and a
-    // detect that trickles in over 0.3 ms no longer has a step's slack to finish in.
-    static const int allow = getenv("PB_FINE_GRAINED") ? atoi(getenv("PB_FINE_GRAINED")) : 0;
+    // Only in the PB_FG build (libpb_hip_fg.so): bit-exact (the pipelined parity tests pass with it), but measured
+    // slower -- 0.647 - 0.655 against 0.632 ms per step in 40-step regions on the same box (profiles/r04_notes.md):
+    // detect's workgroups of batch k + 1 can only start when batch k's have all left, by then the channeliser has taken
+    // their places, and a detect that trickles in over 0.3 ms no longer has a step's slack to finish in.
+    static const int allow = PB_FG && (getenv("PB_FINE_GRAINED") ? atoi(getenv("PB_FINE_GRAINED")) : 1);
     static const int overlap_detect = getenv("PB_OVERLAP_DETECT") ? atoi(getenv("PB_OVERLAP_DETECT")) : 1;
     return allow && overlap_detect && pb_fused_kurtosis(h) && h->sets.size() >= 2 && h->A == 1 && h->S <= PB_FG_MAXSEG &&
            h->d_ready != nullptr;
@@ -988,7 +988,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
     // Row-ready counters: this batch brings every segment slot it uses one epoch further (the channeliser adds one per
     // finished row, detect waits for chunk_rows x epoch).  Booked before either kernel is queued.
     // (PB_FINE_GRAINED=2, timing experiments: the channeliser signals its rows, detect still waits for the event)
-    static const int fg_mode = getenv("PB_FINE_GRAINED") ? atoi(getenv("PB_FINE_GRAINED")) : 0;
+    static const int fg_mode = getenv("PB_FINE_GRAINED") ? atoi(getenv("PB_FINE_GRAINED")) : 1;
     const bool fine = pb_fine_grained(h) && (int)h->sets.size() >= 2 && fg_mode != 2;
     if (fine)
         for (int i = 0; i < nseg; ++i) h->ready_epoch[h->cur_set][i] += 1;

@@ -132,10 +132,16 @@ struct pb_handle {
 // front of it: in-library FFT, rectangular window, an RFI mode that flags, no statistics kept.  PB_FUSE_KURTOSIS=0
 // keeps the two kernels (timing experiments).
 bool pb_fused_kurtosis(const pb_handle *h);
+// PB_FG: the library is built WITH the fine-grained coupling below (libpb_hip_fg.so, `make fg`): plane stores written
+// through to the fabric and detect's loads at system scope, which the ordinary build does not pay for (the written-
+// through stores show as +9 % HBM write traffic in the PMC counters; the step does not change).
+#ifndef PB_FG
+#define PB_FG 0
+#endif
 // detect runs beside the channeliser of its OWN batch, chunk by chunk behind it (row-ready counters), instead of
 // after it: the fused in-library-FFT path with two or more buffer sets, one antenna per handle, at most 16 segments
-// per call.  An experiment that is bit-exact but did not pay: only with PB_FINE_GRAINED=1 (default: the event between
-// the two kernels).
+// per call.  An experiment that is bit-exact but did not pay (profiles/r04_notes.md): only in the PB_FG build, where
+// PB_FINE_GRAINED=0 switches back to the event between the two kernels.
 bool pb_fine_grained(const pb_handle *h);
 #define PB_FG_MAXSEG 16
 
