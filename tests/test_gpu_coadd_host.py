@@ -41,8 +41,10 @@ def _dump(path, data, station):
             f.write(vdif.frame_block(p0, p1, 3600 + s, 33, station).tobytes())
 
 
-@pytest.mark.parametrize("nbit", [8, 2])
-def test_two_ranks_four_antennas_coadded_fil_is_byte_exact(tmp_path, oracle, nbit):
+@pytest.mark.parametrize("nbit,NANT", [(8, 4), (2, 3)])
+def test_two_ranks_four_antennas_coadded_fil_is_byte_exact(tmp_path, oracle, nbit, NANT):
+    """(8 bit, 4 antennas: two per rank, scale exactly 1/2; 2 bit, 3 antennas: ranks hold {0, 2} and {1}, scale
+    float(1 / sqrt 3))"""
     nsec = 4                                         # -> 3 s out (the last second of every stream is dropped)
     data = [make_input(80 + a, R, nsec * SEG, rfi=a != 1, dropped=a == 2) for a in range(NANT)]
     dumps = []
@@ -70,7 +72,8 @@ def test_two_ranks_four_antennas_coadded_fil_is_byte_exact(tmp_path, oracle, nbi
     scale = np.float32(1.0 / np.sqrt(float(NANT)))
     want = b""
     for s in range(nseg):
-        tot = ((np.float32(0) + planes[0][s]) + planes[2][s]) + ((np.float32(0) + planes[1][s]) + planes[3][s])
+        part1 = (np.float32(0) + planes[1][s]) + (planes[3][s] if NANT > 3 else np.float32(0))
+        tot = ((np.float32(0) + planes[0][s]) + planes[2][s]) + part1
         want += oracle.sel_and_dig(tot * scale, R, npol=1, nbit=nbit).tobytes()
     co_hdr = sigproc.sigproc_header(99, 0.8718, -0.72452, "B0833-45", dmjd, 1, nbit)
     co = (tmp_path / "20160701_010000_muos_ea99_kur.fil").read_bytes()
@@ -106,3 +109,34 @@ def test_single_rank_coadd_of_two_antennas_equals_two_rank_sum(tmp_path, oracle)
     co_hdr = sigproc.sigproc_header(99, 0.8718, -0.72452, "B0833-45", 57570 + 3600 / 86400., 1, 8)
     assert (tmp_path / "20160701_010000_muos_ea99_kur.fil").read_bytes() == co_hdr + want
     assert not (tmp_path / ("20160701_010000_muos_ea%02d.fil" % STATIONS[0])).exists()      # -w 0
+
+
+@pytest.mark.parametrize("rfi_mode,npol", [(0, 1), (2, 2)])
+def test_single_rank_coadd_other_modes(tmp_path, oracle, rfi_mode, npol):
+    """RFI mode 0 (the raw stream is what is summed; the coadded file is `_ea99.fil`) and -P 2 (two-pol output:
+    [time][pol][channel] bytes, nifs = 2): two antennas on one rank against the oracle."""
+    nsec = 3
+    data = [make_input(95 + a, R, nsec * SEG) for a in range(2)]
+    dumps = []
+    for a in range(2):
+        p = str(tmp_path / ("ant%d.uw" % a))
+        _dump(p, data[a], STATIONS[a])
+        dumps.append(p)
+    cmd = [sys.executable, os.path.join(ROOT, "vlite-fast_amd", "coadd_host.py"), "--replay"] + dumps + [
+        "-b", "8", "-r", str(rfi_mode), "-P", str(npol), "-w", "2", "--datadir", str(tmp_path), "--logdir", str(tmp_path / "logs"),
+        "--rows-per-seg", str(R)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    nseg = (nsec - 1) * SEG
+    res = [oracle_run(oracle, data[a][:nseg], R, rfi_mode=rfi_mode, npol=npol, nbit=8)[0] for a in range(2)]
+    key = "ave_raw" if rfi_mode == 0 else "ave_kur"
+    scale = np.float32(1.0 / np.sqrt(2.0))
+    want = b"".join(oracle.sel_and_dig(((np.float32(0) + getattr(res[0][s], key)) + getattr(res[1][s], key)) * scale, R, npol=npol).tobytes()
+                    for s in range(nseg))
+    co_hdr = sigproc.sigproc_header(99, 0.8718, -0.72452, "B0833-45", 57570 + 3600 / 86400., npol, 8)
+    name = "20160701_010000_muos_ea99%s.fil" % ("" if rfi_mode == 0 else "_kur")
+    assert (tmp_path / name).read_bytes() == co_hdr + want
+    # the antennas' own files as process_baseband writes them in that mode
+    hdr = sigproc.sigproc_header(STATIONS[0], 0.8718, -0.72452, "B0833-45", 57570 + 3600 / 86400., npol, 8)
+    own = tmp_path / ("20160701_010000_muos_ea%02d%s.fil" % (STATIONS[0], ""))
+    assert own.read_bytes() == hdr + b"".join(x.codes_raw.tobytes() for x in res[0])
