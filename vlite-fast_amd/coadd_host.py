@@ -122,7 +122,7 @@ def run(args, rank=0, world=1, local=0, rings=None, handle=None, dist=None, devi
     pbmod.validate(argparse.Namespace(nbit=args.nbit, rfi_mode=args.rfi_mode, npol=args.npol, rows_per_seg=args.rows_per_seg,
                                       gpu_id=local))
     cmod = importlib.import_module(_pkg + ".coadd")
-    nant = len(args.replay) if args.replay else (len(args.keys_in) if args.keys_in else (args.nant if hasattr(args, "nant") else 0))
+    nant = len(args.replay) if args.replay else len(args.keys_in or ())
     if nant < world:
         raise SystemExit("coadd_host: %d antenna stream(s) for %d ranks; every rank needs at least one" % (nant, world))
     mine = cmod.antennas_of_rank(nant, rank, world)
