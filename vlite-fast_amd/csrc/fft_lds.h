@@ -349,6 +349,12 @@ __device__ __forceinline__ void store_plane4(float *row, int c4, float a, float 
 {
     typedef float f4s __attribute__((ext_vector_type(4)));
     const f4s v = {a, b, c, d};
+#ifdef CH_ABL
+#if CH_ABL & 2
+    if (a == 123.456f) *(f4s *)(row + c4) = v;      // (experiments: the stores are compiled but never executed)
+    return;
+#endif
+#endif
 #if PB_NT_STORES == 2
     // Written through to the fabric (system scope) without allocating in this die's L2: a reader on another die that
     // learns from an atomic counter that the row is complete sees it without a cache write-back in between.  (A

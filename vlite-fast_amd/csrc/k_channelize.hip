@@ -45,6 +45,10 @@ extern "C" int pb_internal_ch_stamps(unsigned long long *out)
 #include "fft_lds.h"
 #include "kurtosis_dev.h"
 
+#ifndef CH_ABL
+#define CH_ABL 0      // energy / timing experiments (variant builds only, results invalid): 1 no moments of the statistic,
+                      // 2 no plane stores, 4 no spectrum step, 8 no FFT passes, 16 no staging / unpack of the transforms
+#endif
 struct ChanArgs {
     const uint8_t *in;      // [A][S][2][seg_samples]
     size_t in_ant_stride, seg_samples;
@@ -172,7 +176,14 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
             tq[i][1] = *(const float4 *)(a.postc + tid * 4 + 1024 * i + 2);
         }
     };
+#if CH_ABL & 8
+    load_tq();
+    if (tid < 250)
+        for (int r = 0; r < 25; ++r) buf[tid * 25 + r] = v[r];
+    __syncthreads();
+#else
     fft6250(v, buf, (const f2 *)a.tw2, (const f2 *)a.tw3, tid, load_tq);
+#endif
     if (DEFER) {
         // (written by wave 0 before the barrier in front of pass 1)
         mask = __builtin_amdgcn_readfirstlane(smw[0]);
@@ -197,7 +208,7 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
     // channel per lane would spare the 8-way LDS bank conflicts of these reads, but its 4-byte stores
     // measured 9 % slower overall)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ((CH_ABL & 4) ? 0 : 4); ++i) {
         const int c4 = tid * 4 + 1024 * i;
         const float4 t01 = tq[i][0], t23 = tq[i][1];
         const f2 tw[4] = {mk2(t01.x, t01.y), mk2(t01.z, t01.w), mk2(t23.x, t23.y), mk2(t23.z, t23.w)};
@@ -401,28 +412,48 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
         auto leaves = [&](int bi, float &r2, float &r4) __attribute__((always_inline)) {
             const int pol = bi >= 25 ? 1 : 0, blk = bi - 25 * pol;
             const uint8_t *sb = (const uint8_t *)(pol ? sraw1 : sraw0) + (pol ? off1 : off0) + blk * PB_NKURTO;
-            float d2[4], d4[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int t = lane + 64 * i;
-                const bool in = t < 250;
-                const int tt = in ? t : 0;
-                f2k u;
-                u.x = (float)sb[tt];
-                u.y = (float)sb[tt + 250];
-                const f2k k128 = {0.0078125f, 0.0078125f}, m1 = {-1.0f, -1.0f};
-                const f2k x = __builtin_elementwise_fma(u, k128, m1);
-                const f2k aa = x * x;
-                const f2k a2 = aa * aa;
-                const float e4 = a2.x + a2.y, e2 = aa.x + aa.y;
-                d4[i] = in ? e4 : 0.f;
-                d2[i] = in ? e2 : 0.f;
+            // Leaves t = lane + 64 i (i = 0..3; i = 3 only for lane < 58) and their partners t + 250.  Two LEAVES share
+            // a packed register -- (t0, t1) and (t2, t3), partners likewise -- so that the pair sums x[t]^2 + x[t+250]^2
+            // of two leaves are one packed add, and level 128 of the tree, (d0 + d2, d1 + d3), another; level 64 adds
+            // the halves.  The same additions on the same operands as one leaf pair per register (which spent a
+            // scalar add per leaf and moment on the pair sum): 30 instead of 44 vector instructions per block.
+            const bool in3 = lane < 250 - 192;
+            const int t3 = in3 ? lane + 192 : 0;
+            f2k uA, uB, uC, uD;
+#if CH_ABL & 32
+            {   // (energy experiment, results invalid: the same conversions fed by two dword reads instead of eight byte reads)
+                const unsigned w0 = ((const unsigned *)((const uint8_t *)(pol ? sraw1 : sraw0) + blk * PB_NKURTO))[lane];
+                const unsigned w1 = ((const unsigned *)((const uint8_t *)(pol ? sraw1 : sraw0) + blk * PB_NKURTO))[lane + 62];
+                uA.x = (float)(w0 & 0xff); uA.y = (float)((w0 >> 8) & 0xff); uB.x = (float)(w1 & 0xff); uB.y = (float)((w1 >> 8) & 0xff);
+                uC.x = (float)((w0 >> 16) & 0xff); uC.y = (float)(w0 >> 24); uD.x = (float)((w1 >> 16) & 0xff); uD.y = (float)(w1 >> 24);
+                (void)sb; (void)t3;
             }
-            r2 = (d2[0] + d2[2]) + (d2[1] + d2[3]);
-            r4 = (d4[0] + d4[2]) + (d4[1] + d4[3]);
+#else
+            uA.x = (float)sb[lane];
+            uA.y = (float)sb[lane + 64];
+            uB.x = (float)sb[lane + 250];
+            uB.y = (float)sb[lane + 314];
+            uC.x = (float)sb[lane + 128];
+            uC.y = (float)sb[t3];
+            uD.x = (float)sb[lane + 378];
+            uD.y = (float)sb[t3 + 250];
+#endif
+            const f2k k128 = {0.0078125f, 0.0078125f}, m1 = {-1.0f, -1.0f};
+            const f2k xA = __builtin_elementwise_fma(uA, k128, m1), xB = __builtin_elementwise_fma(uB, k128, m1);
+            const f2k xC = __builtin_elementwise_fma(uC, k128, m1), xD = __builtin_elementwise_fma(uD, k128, m1);
+            const f2k aA = xA * xA, aB = xB * xB, aC = xC * xC, aD = xD * xD;
+            const f2k qA = aA * aA, qB = aB * aB, qC = aC * aC, qD = aD * aD;
+            const f2k e2ab = aA + aB, e4ab = qA + qB;        // (d[0], d[1])
+            f2k e2cd = aC + aD, e4cd = qC + qD;              // (d[2], d[3])
+            e2cd.y = in3 ? e2cd.y : 0.f;
+            e4cd.y = in3 ? e4cd.y : 0.f;
+            const f2k l2 = e2ab + e2cd, l4 = e4ab + e4cd;    // (d0 + d2, d1 + d3)
+            r2 = l2.x + l2.y;
+            r4 = l4.x + l4.y;
         };
-        const int bi0 = wave * 12 + min(wave, 2), bi1 = bi0 + (wave < 2 ? 13 : 12);
+        const int bi0 = wave * 12 + min(wave, 2), bi1 = (CH_ABL & 1) ? bi0 : bi0 + (wave < 2 ? 13 : 12);
         int bi = bi0;
+        if (CH_ABL & 1) { if (tid < 50) { s2[tid] = 8.7f; s4[tid] = 0.45f; } }
         for (; bi + 4 <= bi1; bi += 4) {
             float a2, a4, b2, b4, c2, c4, e2, e4;
             leaves(bi, a2, a4);

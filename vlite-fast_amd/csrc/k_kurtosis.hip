@@ -98,26 +98,35 @@ __global__ __launch_bounds__(256, 6) void k_kurtosis_row(
     // kernel is bound by vector issue in this loop).
     auto leaves = [&](int bi, float &r2, float &r4) __attribute__((always_inline)) {
         const int pol = bi >= 25 ? 1 : 0, blk = bi - 25 * pol;
-        const uint8_t *sb = (const uint8_t *)sraw[pol] + (pol ? off1 : off0) + blk * PB_NKURTO;
-        float d2[4], d4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int t = lane + 64 * i;
-            const bool in = t < 250;
-            const int tt = in ? t : 0;
-            f2k u;
-            u.x = (float)sb[tt];
-            u.y = (float)sb[tt + 250];
-            const f2k k128 = {0.0078125f, 0.0078125f}, m1 = {-1.0f, -1.0f};
-            const f2k x = __builtin_elementwise_fma(u, k128, m1);
-            const f2k a = x * x;
-            const f2k a2 = a * a;
-            const float e4 = a2.x + a2.y, e2 = a.x + a.y;
-            d4[i] = in ? e4 : 0.f;
-            d2[i] = in ? e2 : 0.f;
-        }
-        r2 = (d2[0] + d2[2]) + (d2[1] + d2[3]);
-        r4 = (d4[0] + d4[2]) + (d4[1] + d4[3]);
+        const uint8_t *sb = (const uint8_t *)(sraw[pol]) + (pol ? off1 : off0) + blk * PB_NKURTO;
+        // Leaves t = lane + 64 i (i = 0..3; i = 3 only for lane < 58) and their partners t + 250.  Two LEAVES share
+        // a packed register -- (t0, t1) and (t2, t3), partners likewise -- so that the pair sums x[t]^2 + x[t+250]^2
+        // of two leaves are one packed add, and level 128 of the tree, (d0 + d2, d1 + d3), another; level 64 adds
+        // the halves.  The same additions on the same operands as one leaf pair per register (which spent a
+        // scalar add per leaf and moment on the pair sum): 30 instead of 44 vector instructions per block.
+        const bool in3 = lane < 250 - 192;
+        const int t3 = in3 ? lane + 192 : 0;
+        f2k uA, uB, uC, uD;
+        uA.x = (float)sb[lane];
+        uA.y = (float)sb[lane + 64];
+        uB.x = (float)sb[lane + 250];
+        uB.y = (float)sb[lane + 314];
+        uC.x = (float)sb[lane + 128];
+        uC.y = (float)sb[t3];
+        uD.x = (float)sb[lane + 378];
+        uD.y = (float)sb[t3 + 250];
+        const f2k k128 = {0.0078125f, 0.0078125f}, m1 = {-1.0f, -1.0f};
+        const f2k xA = __builtin_elementwise_fma(uA, k128, m1), xB = __builtin_elementwise_fma(uB, k128, m1);
+        const f2k xC = __builtin_elementwise_fma(uC, k128, m1), xD = __builtin_elementwise_fma(uD, k128, m1);
+        const f2k aA = xA * xA, aB = xB * xB, aC = xC * xC, aD = xD * xD;
+        const f2k qA = aA * aA, qB = aB * aB, qC = aC * aC, qD = aD * aD;
+        const f2k e2ab = aA + aB, e4ab = qA + qB;        // (d[0], d[1])
+        f2k e2cd = aC + aD, e4cd = qC + qD;              // (d[2], d[3])
+        e2cd.y = in3 ? e2cd.y : 0.f;
+        e4cd.y = in3 ? e4cd.y : 0.f;
+        const f2k l2 = e2ab + e2cd, l4 = e4ab + e4cd;    // (d0 + d2, d1 + d3)
+        r2 = l2.x + l2.y;
+        r4 = l4.x + l4.y;
     };
     // 13, 13, 12, 12 blocks
     const int bi0 = wave * 12 + min(wave, 2), bi1 = bi0 + (wave < 2 ? 13 : 12);

@@ -1004,7 +1004,10 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         }
     } else {
         StageTimer t(h, PB_ST_CHANNELIZE);
-        HIPCHK(h, h->cfg.taps == 4 ? launch_channelize_pfb(h, nseg, inject_now) : launch_channelize(h, nseg, inject_now));
+        // (PB_SKIP=1 / 2, energy experiments only -- tools/energy_probe.py: leave out the channeliser / detect launch)
+        static const int skip = getenv("PB_SKIP") ? atoi(getenv("PB_SKIP")) : 0;
+        if (!(skip & 1))
+            HIPCHK(h, h->cfg.taps == 4 ? launch_channelize_pfb(h, nseg, inject_now) : launch_channelize(h, nseg, inject_now));
         t.stop();
     }
     HIPCHK(h, hipEventRecord(h->ev_fftdone, h->stream));
@@ -1028,7 +1031,8 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         h->stream = h->s_det;
         if (e2 == hipSuccess) {
             StageTimer t(h, PB_ST_DETECT);
-            e2 = launch_detect(h, nseg, inject_now, fine);
+            static const int skip_det = getenv("PB_SKIP") ? atoi(getenv("PB_SKIP")) & 2 : 0;
+            if (!skip_det) e2 = launch_detect(h, nseg, inject_now, fine);
             t.stop();
         }
         if (e2 == hipSuccess) e2 = hipEventRecord(h->ev_chan, h->s_det);   // this set's kernels are done
