@@ -15,6 +15,9 @@
                          // pass-2 arithmetic (bit 1) or between that arithmetic and its LDS stores (bit 2)
 #endif
 
+#ifndef FFT_ABL
+#define FFT_ABL 0       // energy experiments (variant builds only, results invalid): 1 no butterfly arithmetic, 2 no LDS exchange
+#endif
 #ifndef FFT_STAMP
 #define FFT_STAMP(i)   // timing experiments: a variant build records the wave's clock at phase boundary i
 #endif
@@ -203,14 +206,16 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
 #endif
     // pass 1: R = 25, Ns = 1
     if (tid < 250) {
-        dft25(v);
+        if (!(FFT_ABL & 1)) dft25(v);
+        if (!(FFT_ABL & 2)) {
 #pragma unroll
-        for (int r = 0; r < 25; ++r) buf[tid * 25 + r] = v[r];
+            for (int r = 0; r < 25; ++r) buf[tid * 25 + r] = v[r];
+        }
     }
     __syncthreads();
     FFT_STAMP(3);
     // pass 2: R = 25, Ns = 25
-    if (tid < 250) {
+    if (tid < 250 && !(FFT_ABL & 2)) {
 #pragma unroll
         for (int r = 0; r < 25; ++r) v[r] = buf[tid + 250 * r];
     }
@@ -222,16 +227,17 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
 #if FFT_PREFETCH & 2
     load_t3();
 #endif
-    if (tid < 250) {
+    if (tid < 250 && !(FFT_ABL & 1)) {
 #pragma unroll
         for (int r = 1; r < 25; r += 4)
             cmul4(v[r], v[r + 1], v[r + 2], v[r + 3], t2[r - 1], t2[r], t2[r + 1], t2[r + 2]);
         dft25(v);
     }
+    if (FFT_ABL & 1) { v[0] = v[0] + t2[0] + t2[23]; }
 #if FFT_PREFETCH & 4
     load_t3();   // after the pass-2 arithmetic (the register peak), before its LDS stores and the barrier
 #endif
-    if (tid < 250) {
+    if (tid < 250 && !(FFT_ABL & 2)) {
         const int j0 = (tid / 25) * 625 + k;
 #pragma unroll
         for (int r = 0; r < 25; ++r) buf[j0 + 25 * r] = v[r];
@@ -274,7 +280,7 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
         const int j = tid + 256 * i;
         if (j < 625) {
 #pragma unroll
-            for (int r = 0; r < 10; ++r) u[i][r] = buf[j + 625 * r];
+            for (int r = 0; r < 10; ++r) u[i][r] = (FFT_ABL & 2) ? v[(r + i) % 25] : buf[j + 625 * r];
         }
     }
 #if !(FFT_PREFETCH & 6) && !defined(FFT_LEAN)
@@ -284,13 +290,19 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
     for (int i = 0; i < 3; ++i) {
         const int j = tid + 256 * i;
         if (j < 625) {
-            cmul4(u[i][1], u[i][2], u[i][3], u[i][4], t3[i][0], t3[i][1], t3[i][2], t3[i][3]);
-            cmul4(u[i][5], u[i][6], u[i][7], u[i][8], t3[i][4], t3[i][5], t3[i][6], t3[i][7]);
-            u[i][9] = cmul(u[i][9], t3[i][8]);
+            if (!(FFT_ABL & 1)) {
+                cmul4(u[i][1], u[i][2], u[i][3], u[i][4], t3[i][0], t3[i][1], t3[i][2], t3[i][3]);
+                cmul4(u[i][5], u[i][6], u[i][7], u[i][8], t3[i][4], t3[i][5], t3[i][6], t3[i][7]);
+                u[i][9] = cmul(u[i][9], t3[i][8]);
+            } else {
+                u[i][0] = u[i][0] + t3[i][0] + t3[i][8];
+            }
             if (i == 0) in_pass3();
-            dft10(u[i]);
+            if (!(FFT_ABL & 1)) dft10(u[i]);
+            if (!(FFT_ABL & 2) || i == 0) {
 #pragma unroll
-            for (int r = 0; r < 10; ++r) buf[j + 625 * r] = u[i][r];
+                for (int r = 0; r < 10; ++r) buf[j + 625 * r] = u[i][r];
+            }
         }
     }
 #endif
