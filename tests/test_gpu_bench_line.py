@@ -38,6 +38,16 @@ def test_bench_line_fields_and_consistency():
     assert r["avg_launch_ms"] <= d["ms_per_step"] * 1.05            # a kernel of the step cannot outlast the step
     assert 0.05 < r["frac"] < 1.0 and 0.05 < r["pipeline"]["frac"] < 1.0
     assert r["kernel"] == "channelize" and "kurtosis" not in d["stage_ms_per_step"]      # the channeliser flags its own rows
+    # what the step runs into (round 4): the package power cap, reported beside the pipes
+    pw = r["power"]
+    if "error" not in pw:                   # (amdsmi may be unavailable to an unprivileged user on some hosts)
+        assert 300 < pw["socket_w"] <= pw["cap_w"] * 1.02 and pw["cap_w"] >= 500
+        assert 500 <= pw["gfx_mhz"] <= 2500 and 0.0 <= pw["power_throttle_residency"] <= 1.0
+    v = r["valu"]
+    if v is not None:                       # (None when no committed PMC summary matches the kernels' source hash)
+        assert "error" not in v, v
+        assert 0.05 < v["frac"] < 1.0 and v["insts_per_step"] > 1e8
+        assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Msamp/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] / c["value"] > 50                                # (reported only; sanity of units)
