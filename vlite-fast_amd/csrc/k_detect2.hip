@@ -203,7 +203,11 @@ __device__ __forceinline__ void phase_b_rows(BState<NPOL> &s, int h)
             const float un = jj == 0 ? u4.x : (jj == 1 ? u4.y : (jj == 2 ? u4.z : u4.w));     // bp after the row
             const float ub = jj == 0 ? ub4 : (jj == 1 ? u4.x : (jj == 2 ? u4.y : u4.z));      // bp before the row
             const float p = h ? s.p[pol][4 + jj] : s.p[pol][jj];
+#if defined(D2_ABL) && (D2_ABL & 1)
+            float v = p * un - 1.f;          // (energy experiment, results invalid: what the IEEE divisions cost)
+#else
             float v = p / un - 1.f;
+#endif
             if (KUR) {
                 v = p > ub * 11.f ? 10.f : v;          // the recurrence wave's own test (:490-491): clipped -> 10
                 v = w == 0.f ? 0.f : v;                // :474-476
