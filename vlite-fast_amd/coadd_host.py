@@ -126,7 +126,12 @@ def run(args, rank=0, world=1, local=0, rings=None, handle=None, dist=None, devi
     if nant < world:
         raise SystemExit("coadd_host: %d antenna stream(s) for %d ranks; every rank needs at least one" % (nant, world))
     mine = cmod.antennas_of_rank(nant, rank, world)
-    log = pbmod.Log(args.logdir, args.stdout_output)
+    _log = pbmod.Log(args.logdir, args.stdout_output)
+
+    def log(level, msg):
+        _log(level, msg)
+        if level == "ERR" and not args.stdout_output:       # (a rank that gives up says why where the launcher shows it)
+            print("coadd_host rank %d: %s" % (rank, msg), file=sys.stderr)
     log("INFO", "[COADD_HOST] rank %d of %d, antennas %s, invoked with: \n%s" % (rank, world, mine, " ".join(sys.argv)))
     R = args.rows_per_seg
     frames_per_sec = R * SEG_PER_SEC * 12500 // vdif.VD_DAT

@@ -179,11 +179,14 @@ def main(argv=None):
     ap.add_argument("-f", dest="rfi", action="store_true")
     ap.add_argument("-e", dest="to_disk", action="store_true")   # always to disk here
     ap.add_argument("--out", default="baseband_sim.uw")
+    ap.add_argument("--unix-time", type=int, default=None,
+                    help="extension: start of the observation (default: now, as the reference stamps it); several "
+                         "antennas' dumps that are to be coadded need the same one")
     a = ap.parse_args(argv)
     for i in range(a.nobs):
         path = a.out if a.nobs == 1 else "%s.%d" % (a.out, i)
         n = write_observation(path, generate(a.tobs, a.dm, a.period, a.ampl, a.poln_ratio, a.seed + i, a.rfi,
-                                             a.skip_period), int(time.time()))
+                                             a.skip_period), int(time.time()) if a.unix_time is None else a.unix_time)
         print("wrote %s: %d frames per thread" % (path, n))
 
 
