@@ -140,3 +140,36 @@ def test_single_rank_coadd_other_modes(tmp_path, oracle, rfi_mode, npol):
     hdr = sigproc.sigproc_header(STATIONS[0], 0.8718, -0.72452, "B0833-45", 57570 + 3600 / 86400., npol, 8)
     own = tmp_path / ("20160701_010000_muos_ea%02d%s.fil" % (STATIONS[0], ""))
     assert own.read_bytes() == hdr + b"".join(x.codes_raw.tobytes() for x in res[0])
+
+
+def test_fullsize_coadd_two_antennas_one_second(tmp_path, oracle):
+    """R = 1024 (the production segment; the two-antennas-per-GPU shape of configs[3]): two 2-s dumps -> one coadded
+    second, against the oracle's 2 x 10 full-size segments."""
+    Rf, nsec = 1024, 2
+    data = [make_input(60 + a, Rf, nsec * SEG, rfi=a == 0, dropped=a == 1) for a in range(2)]
+    dumps = []
+    for a in range(2):
+        p = str(tmp_path / ("ant%d.uw" % a))
+        hdr = vdif.writer_header(STATIONS[a], 0.8718, -0.72452, "B0833-45", 58000.0, "19A-331", 33, 3600)
+        with open(p, "wb") as f:
+            f.write(vdif.ascii_header_format(hdr))
+            for s in range(nsec):
+                p0 = np.concatenate([data[a][s * SEG + i, 0] for i in range(SEG)])
+                p1 = np.concatenate([data[a][s * SEG + i, 1] for i in range(SEG)])
+                f.write(vdif.frame_block(p0, p1, 3600 + s, 33, STATIONS[a]).tobytes())
+        dumps.append(p)
+    cmd = [sys.executable, os.path.join(ROOT, "vlite-fast_amd", "coadd_host.py"), "--replay"] + dumps + [
+        "-b", "8", "-r", "2", "-w", "2", "--datadir", str(tmp_path), "--logdir", str(tmp_path / "logs")]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    nseg = (nsec - 1) * SEG
+    res = [oracle_run(oracle, data[a][:nseg], Rf)[0] for a in range(2)]
+    scale = np.float32(1.0 / np.sqrt(2.0))
+    want = b"".join(oracle.sel_and_dig(((np.float32(0) + res[0][s].ave_kur) + res[1][s].ave_kur) * scale, Rf).tobytes() for s in range(nseg))
+    dmjd = 57570 + 3600 / 86400.
+    co_hdr = sigproc.sigproc_header(99, 0.8718, -0.72452, "B0833-45", dmjd, 1, 8)
+    assert (tmp_path / "20160701_010000_muos_ea99_kur.fil").read_bytes() == co_hdr + want
+    for a in range(2):
+        hdr = sigproc.sigproc_header(STATIONS[a], 0.8718, -0.72452, "B0833-45", dmjd, 1, 8)
+        assert (tmp_path / ("20160701_010000_muos_ea%02d_kur.fil" % STATIONS[a])).read_bytes() == hdr + b"".join(x.codes_kur.tobytes() for x in res[a])
+        assert (tmp_path / ("20160701_010000_muos_ea%02d.fil" % STATIONS[a])).read_bytes() == hdr + b"".join(x.codes_raw.tobytes() for x in res[a])
