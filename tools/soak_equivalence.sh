@@ -26,4 +26,25 @@ for f in $D/nat_fused/*.fil; do
     done
     ls -la "$f"
 done
+# round 4: the fine-grained-coupling build of the library (when built) must give the same files, and the coadder host on
+# this ONE antenna a coadded file whose payload is the antenna's excised stream (scale 1 / sqrt 1)
+if [ -f vlite-fast_amd/csrc/libpb_hip_fg.so ]; then
+    run py_fg PB_LIBPATH=$PWD/vlite-fast_amd/csrc/libpb_hip_fg.so python -m vlite-fast_amd.process_baseband
+    for f in $D/nat_fused/*.fil; do cmp "$f" "$D/py_fg/$(basename $f)" || ok=0; done
+fi
+mkdir -p $D/co
+python vlite-fast_amd/coadd_host.py --replay $D/dump.vdif -w 0 -b 8 -r 2 --datadir $D/co --logdir $D/co > $D/co/log 2>&1
+python3 - $D <<'PY' || ok=0
+import glob, importlib, sys
+sys.path.insert(0, ".")
+sp = importlib.import_module("vlite-fast_amd.sigproc")
+d = sys.argv[1]
+kur = open(glob.glob(d + "/nat_fused/*_kur.fil")[0], "rb").read()
+co = open(glob.glob(d + "/co/*_ea99_kur.fil")[0], "rb").read()
+hk, nk = sp.read_header(kur)
+hc, nc = sp.read_header(co)
+assert hc["telescope_id"] == 99 and {k: v for k, v in hk.items() if k != "telescope_id"} == {k: v for k, v in hc.items() if k != "telescope_id"}
+assert kur[nk:] == co[nc:], "coadd of one antenna differs from its excised stream"
+print("coadd_host on one antenna: payload = the antenna's _kur.fil (%d bytes)" % (len(co) - nc))
+PY
 [ $ok = 1 ] && echo "soak_equivalence: $T s, all .fil files identical" || { echo "soak_equivalence: MISMATCH"; exit 1; }
