@@ -955,7 +955,10 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         if (e == hipSuccess && !fused) {
             {
                 StageTimer t(h, PB_ST_KURTOSIS);
-                e = launch_kurtosis_flag(h, nseg, hipfft);
+                static const int skip_kur = getenv("PB_SKIP") ? atoi(getenv("PB_SKIP")) & 4 : 0;   // (energy experiments)
+                // (only once the set holds the flags of the same input from an earlier call: the experiment re-processes
+                //  one second of data, and without flags there would be no excised transforms either)
+                if (!(skip_kur && h->processed > 0)) e = launch_kurtosis_flag(h, nseg, hipfft);
                 t.stop();
             }
             // taps = 4: the weights read the flags of the previous batch's last rows (history slot hist_rd, filled by
