@@ -51,7 +51,7 @@ NL = 24 if PIPE else 4
 t = buf4[(NL - 3 if PIPE else NL - 1) & 3][:NWG].astype(np.int64)
 print("rc", rc, "k_channelize_kur %.4f ms per launch %s, %d workgroups (stamps: the last launch)" % (ms, "in the pipeline" if PIPE else "alone", NWG))
 names = ["both rows requested -> staged in LDS (barrier)", "moments of the 50 blocks (barrier)",
-         "D'Agostino scores, 50 lanes (barrier)", "flags, ballot, weight, broadcast (2 barriers)",
+         "flags in wave 0 only (waves 1-3 unpack pol 0)", "(mask / weight hand-over: no barrier now)   ",
          "transforms of pol 0 and pol 1"]
 for label, sel in (("rows without flags (2 transforms)", t[:, 6] == 0), ("rows with flags (4 transforms)", t[:, 6] != 0)):
     d = np.diff(t[sel, :6], axis=1).astype(np.float64)
