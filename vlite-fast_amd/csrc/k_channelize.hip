@@ -386,12 +386,18 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
     // expects them (the start of buf), so that transform stages nothing
     RowStage st;
     unsigned off0, off1;
+    DagConsts dc;
     uint4 *sraw0 = (uint4 *)buf, *sraw1 = (uint4 *)buf + 784;     // 2 x 12 544 B
     float *s2 = (float *)((uint4 *)buf + 2 * 784), *s4 = s2 + 50;
     {
         RowStage sb;
         stage_request(a, tid, seg, row, 0, ant, st);
         stage_request(a, tid, seg, row, 1, ant, sb);
+#ifndef KUR_NO_DAG_PREFETCH
+        // the D'Agostino constants are requested with the rows: their first use is on the critical path of the wave
+        // that decides the flags, and a scalar load from memory is a microsecond there
+        dc = *a.dag;
+#endif
         off0 = (unsigned)(row_byte(a, seg, row, 0, ant) & 15);
         off1 = (unsigned)(row_byte(a, seg, row, 1, ant) & 15);
         const bool l0 = tid + 768 < (int)((off0 + PB_NFFT + 15) >> 4), l1 = tid + 768 < (int)((off1 + PB_NFFT + 15) >> 4);
@@ -511,7 +517,11 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
         if (lane < 50) {
             const float p = s2[lane] / PB_NKURTO;
             const float k = s4[lane] / PB_NKURTO / (p * p);
+#ifndef KUR_NO_DAG_PREFETCH
+            f = dag_flag(k, dc);
+#else
             f = dag_flag(k, *a.dag);
+#endif
         }
         const unsigned long long b = __ballot(f);
         const uint32_t m = (uint32_t)((b | (b >> 25)) & 0x1ffffffull);
