@@ -189,6 +189,11 @@ int pb_output_dev(pb_handle *h, int ant, int stream, void **codes, void **ave);
  * RCCL reduce of d_sum done by the host (torch.distributed); then on the root:
  * codes = sel_and_dig(d_sum / sqrt(nant_total)). */
 int pb_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate);
+/* The same local sum from the batch's QUANTISED codes instead of the fp32 planes: d_sum (+)= sum over antennas of
+ * the centre of each code's quantiser cell, in the fp32 planes' layout (so the reduce and pb_coadd_finish are
+ * unchanged).  This is what a coadder fed from the co rings (writer.c:343-352) can do; offered for like-for-like
+ * comparisons with the fp32 mode, which is the default.  Works with keep_ave = 0. */
+int pb_coadd_local_codes(pb_handle *h, int nseg, float *d_sum, int accumulate);
 /* One antenna per handle (nant = 1, the sharding of BASELINE configs[3] at one antenna per GPU): the plane to
  * be reduced IS the antenna's fp32 plane, so detect can write it straight into the caller's buffer and the local
  * sum needs no kernel at all (a 21-MB copy per second of data that cost 0.085 ms of a 0.68-ms step beside the

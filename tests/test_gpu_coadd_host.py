@@ -173,3 +173,76 @@ def test_fullsize_coadd_two_antennas_one_second(tmp_path, oracle):
         hdr = sigproc.sigproc_header(STATIONS[a], 0.8718, -0.72452, "B0833-45", dmjd, 1, 8)
         assert (tmp_path / ("20160701_010000_muos_ea%02d_kur.fil" % STATIONS[a])).read_bytes() == hdr + b"".join(x.codes_kur.tobytes() for x in res[a])
         assert (tmp_path / ("20160701_010000_muos_ea%02d.fil" % STATIONS[a])).read_bytes() == hdr + b"".join(x.codes_raw.tobytes() for x in res[a])
+
+
+def _levels(codes, nbit, npol, ntime):
+    """bytes in sel_and_dig order -> fp32 cell centres in the planes' layout (include/pb_hip.h: pb_coadd_local_codes)"""
+    b = np.frombuffer(codes, np.uint8) if not isinstance(codes, np.ndarray) else codes.reshape(-1)
+    per = 8 // nbit
+    q = np.stack([(b >> (nbit * j)) & ((1 << nbit) - 1) for j in range(per)], axis=1).reshape(-1).astype(np.float64)
+    if nbit == 8:
+        v = ((q - 127.0) * 0.02957).astype(np.float32)
+    elif nbit == 4:
+        v = ((q - 7.0) * 0.3188).astype(np.float32)
+    else:
+        lv = np.array([-0.6109 - 0.503975, 0.5 * (-0.6109 + 0.3970), 0.5 * (0.3970 + 1.4050), 1.4050 + 0.503975]).astype(np.float32)
+        v = lv[q.astype(np.int64)]
+    if npol == 2:
+        v = v.reshape(ntime, 2, 4096).transpose(1, 0, 2).reshape(-1)
+    return v
+
+
+@pytest.mark.parametrize("nbit,npol,ranks,nant", [(8, 1, 2, 3), (2, 1, 1, 2), (4, 2, 1, 2)])
+def test_coadd_from_quantised_codes(tmp_path, oracle, nbit, npol, ranks, nant):
+    """`--coadd-input codes` (the like-for-like mode): what is summed is each antenna's quantised
+    filterbank -- the bytes of its own _kur.fil, each code standing for the centre of its quantiser cell -- not the
+    fp32 planes.  Expected from the oracle's codes alone; ranks hold {0, 2} and {1}."""
+    nsec = 3
+    data = [make_input(70 + a, R, nsec * SEG, rfi=a != 1) for a in range(nant)]
+    dumps = []
+    for a in range(nant):
+        p = str(tmp_path / ("ant%d.uw" % a))
+        _dump(p, data[a], STATIONS[a])
+        dumps.append(p)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.join(ROOT, "vlite-fast_amd", "coadd_host.py")]
+    if ranks > 1:
+        cmd += ["--ranks", str(ranks), "--dist-backend", "gloo", "--share-gpus"]
+    cmd += ["--coadd-input", "codes", "--replay"] + dumps + ["-b", str(nbit), "-P", str(npol), "-r", "2", "-w", "2",
+            "--datadir", str(tmp_path), "--logdir", str(tmp_path / "logs"), "--rows-per-seg", str(R)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    nseg = (nsec - 1) * SEG
+    res = [oracle_run(oracle, data[a][:nseg], R, rfi_mode=2, npol=npol, nbit=nbit)[0] for a in range(nant)]
+    dmjd = 57570 + 3600 / 86400.
+    for a in range(nant):                  # the antennas' own files are what they always are
+        hdr = sigproc.sigproc_header(STATIONS[a], 0.8718, -0.72452, "B0833-45", dmjd, npol, nbit)
+        fbk = tmp_path / ("20160701_010000_muos_ea%02d_kur.fil" % STATIONS[a])
+        assert fbk.read_bytes() == hdr + b"".join(x.codes_kur.tobytes() for x in res[a])
+    ntime = R // 8
+    scale = np.float32(1.0 / np.sqrt(float(nant)))
+    want, fp32 = b"", b""
+    for s in range(nseg):
+        lv = [_levels(res[a][s].codes_kur, nbit, npol, ntime) for a in range(nant)]
+        if ranks == 2:
+            tot = ((np.float32(0) + lv[0]) + lv[2]) + (np.float32(0) + lv[1])
+        else:
+            tot = (np.float32(0) + lv[0]) + lv[1]
+        full = np.zeros((npol, ntime, oracle.NCHAN), np.float32)      # the oracle's sel_and_dig takes the full band
+        full[:, :, oracle.CHANMIN:oracle.CHANMIN + 4096] = (tot * scale).reshape(npol, ntime, 4096)
+        want += oracle.sel_and_dig(full, R, npol=npol, nbit=nbit).tobytes()
+        p = np.float32(0) + res[0][s].ave_kur
+        for a in range(1, nant):
+            p = p + res[a][s].ave_kur
+        fp32 += oracle.sel_and_dig(p * scale, R, npol=npol, nbit=nbit).tobytes()
+    co_hdr = sigproc.sigproc_header(99, 0.8718, -0.72452, "B0833-45", dmjd, npol, nbit)
+    co = (tmp_path / "20160701_010000_muos_ea99_kur.fil").read_bytes()
+    assert co[:len(co_hdr)] == co_hdr and len(co) - len(co_hdr) == len(want)
+    got = np.frombuffer(co[len(co_hdr):], np.uint8)
+    assert co[len(co_hdr):] == want, "%d coadded bytes differ" % int((got != np.frombuffer(want, np.uint8)).sum())
+    # and it is a different product from the fp32 sum: quantising twice loses what the planes still had
+    assert want != fp32
+    if nbit == 8:
+        d = np.abs(got.astype(np.int32) - np.frombuffer(fp32, np.uint8).astype(np.int32))
+        # (within 2 codes wherever no antenna's byte had clipped; a clipped 0 / 255 has lost its excess for good)
+        assert (d <= 2).mean() > 0.95 and 0.0 < (d > 0).mean() < 0.8

@@ -42,6 +42,11 @@ class IncoherentCoadd(object):
     straight into this object's buffer of the batch's buffer set (pb_set_coadd_target) and the local sum launches
     nothing.  Otherwise pb_coadd_local sums the rank's antennas into one buffer.
 
+    source="codes": the local sum is taken from the antennas' QUANTISED filterbank bytes (each code stands for the
+    centre of its quantiser cell; pb_coadd_local_codes) -- what a coadder fed from the co rings has to work with.
+    The reduce and the root's requantisation are the same.  For like-for-like comparisons; the
+    default sums the fp32 planes.
+
     queue(set_index, nseg): call once the batch in that buffer set is known to be complete on the device (its
     filterbank bytes have been fetched), i.e. one step behind the batch itself -- no device-side wait for detect is
     then queued (a pending cross-stream wait on detect's event was measured to cost the pipeline 0.12 ms per step).
@@ -49,7 +54,13 @@ class IncoherentCoadd(object):
     queue() call, in pinned host memory (waits for that batch's requantisation only).
     """
 
-    def __init__(self, handle, nant_total, device, root=0, backend="nccl", group=None, use_target=None, parts=7):
+    def __init__(self, handle, nant_total, device, root=0, backend="nccl", group=None, use_target=None, parts=7,
+                 source="planes"):
+        if source not in ("planes", "codes"):
+            raise ValueError("source must be 'planes' or 'codes'")
+        self.source = source               # "codes": sum the antennas' quantised bytes (pb_coadd_local_codes)
+        if source == "codes":
+            use_target = False
         self.h = handle
         self.nant_total = int(nant_total)
         self.root = root
@@ -99,7 +110,10 @@ class IncoherentCoadd(object):
         h.select_set(set_index)
         with self._on_stream():
             if self.parts & 1:
-                h.coadd_local(nseg, ds.data_ptr())
+                if self.source == "codes":
+                    h.coadd_local_codes(nseg, ds.data_ptr())
+                else:
+                    h.coadd_local(nseg, ds.data_ptr())
             if self.parts & 2 and self.world > 1:
                 if self.backend == "nccl":
                     if self.timing:

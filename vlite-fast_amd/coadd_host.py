@@ -66,6 +66,8 @@ def build_parser():
     p.add_argument("--ranks", type=int, default=0, help="start this many ranks (one per GPU) as child processes")
     p.add_argument("--master-port", type=int, default=0)
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal: reduce through host memory)")
+    p.add_argument("--coadd-input", choices=["planes", "codes"], default="planes",
+                   help="what is summed: the fp32 planes before quantisation (default) or the antennas' quantised codes")
     p.add_argument("--share-gpus", action="store_true", help="rehearsal only: ranks may wrap onto the cards")
     return p
 
@@ -146,7 +148,7 @@ def run(args, rank=0, world=1, local=0, rings=None, handle=None, dist=None, devi
                              fft_backend=lp.FFT_LDS if args.fft_backend == "lds" else lp.FFT_HIPFFT, rows_per_seg=R,
                              max_seg=SEG_PER_SEC, keep_ave=True, nsets=args.nsets)
     if coadd is None:
-        coadd = cmod.IncoherentCoadd(handle, nant, device, root=0, backend=args.dist_backend)
+        coadd = cmod.IncoherentCoadd(handle, nant, device, root=0, backend=args.dist_backend, source=args.coadd_input)
     ctl = Control(dist, args.dist_backend)
     trim, nsets = handle.trim, handle.nsets
     root = rank == 0

@@ -1214,6 +1214,25 @@ extern "C" int pb_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumula
     return PB_OK;
 }
 
+// The same local sum taken from this batch's quantised codes (coadd_codes.hip): what a coadder fed from the co
+// rings has to work with.  Needs no fp32 planes (keep_ave may be 0).
+hipError_t launch_coadd_local_codes(pb_handle *h, int nseg, float *d_sum, int accumulate, hipStream_t st);
+extern "C" int pb_coadd_local_codes(pb_handle *h, int nseg, float *d_sum, int accumulate)
+{
+    if (!h || !d_sum) return PB_EINVAL;
+    if (nseg < 1 || nseg > h->S) return fail(h, PB_EINVAL, "pb_coadd_local_codes: nseg out of range");
+    if (nseg > h->processed) return fail(h, PB_EINVAL, "pb_coadd_local_codes: more segments than the batch holds");
+    if (h->d_coadd_target && d_sum == h->d_coadd_target)
+        return fail(h, PB_ESTATE, "pb_coadd_local_codes: d_sum is the set's fp32 coadd target");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t cs = h->s_coadd ? h->s_coadd : h->stream;
+    if (hipEventQuery(h->ev_chan) != hipSuccess) HIPCHK(h, hipStreamWaitEvent(cs, h->ev_chan, 0));
+    hipError_t e = launch_coadd_local_codes(h, nseg, d_sum, accumulate, cs);
+    if (e == hipSuccess) e = hipEventRecord(h->ev_cl, cs);      // (the set's next detect writes codes and planes alike)
+    HIPCHK(h, e);
+    return PB_OK;
+}
+
 extern "C" int pb_set_coadd_target(pb_handle *h, float *d_sum)
 {
     if (!h) return PB_EINVAL;
