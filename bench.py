@@ -155,9 +155,11 @@ def measured_traffic(stage, args, taps, A=1):
     import glob
     if args.backend != "lds" or args.rfi_mode != 2 or args.seg_per_step != 10 or A != 1 or args.rfi_frac:
         return None
-    fused = taps == 1 and args.rfi_mode != 0 and os.environ.get("PB_FUSE_KURTOSIS", "1") != "0"
+    # (the library's rule, pb_fused_kurtosis: level 1 fuses the rectangular window only, 2 also taps = 4)
+    fused = args.rfi_mode != 0 and int(os.environ.get("PB_FUSE_KURTOSIS", "1") or 0) >= (1 if taps == 1 else 2)
     names = {"kurtosis": "k_kurtosis_row",
-             "channelize": "k_channelize_pfb" if taps == 4 else ("k_channelize_kur" if fused else "k_channelize"),
+             "channelize": ("k_channelize_pfb_kur" if fused else "k_channelize_pfb") if taps == 4
+                           else ("k_channelize_kur" if fused else "k_channelize"),
              "detect": "k_detect2"}
     want = names.get(stage)
     best = None

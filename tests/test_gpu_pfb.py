@@ -255,8 +255,17 @@ def test_pfb_pipelined_two_sets_mode0_bit_exact(oracle):
     assert np.array_equal(np.concatenate(raw), ref)
 
 
+@pytest.fixture(params=[1, 2], ids=["kurtosis-pass", "fused"])
+def fuse(request, monkeypatch):
+    """PB_FUSE_KURTOSIS as pb_create reads it: 1 = kurtosis pass + weights kernel + k_channelize_pfb (the default for
+    taps = 4), 2 = k_channelize_pfb_kur, the channeliser that flags its own rows and looks back for its predecessors'
+    (bit-exact, measured slower: opt-in)."""
+    monkeypatch.setenv("PB_FUSE_KURTOSIS", str(request.param))
+    return request.param
+
+
 @pytest.mark.parametrize("nsets", [1, 2, 3])
-def test_pfb_rfi_mode2_both_streams_bit_exact(oracle, nsets):
+def test_pfb_rfi_mode2_both_streams_bit_exact(oracle, nsets, fuse):
     """(b) RFI mode 2 as benchmarked: RFI bursts, a row with every block flagged (weight 0 for four output rows'
     window share), a strongly flagged stretch, a dropped frame, three batches (flags of the carried rows are used
     by the next batch).  Raw AND excised codes bit-exact, weights bit-exact.  nsets = 3: the kurtosis pass of batch k + 1
@@ -283,7 +292,7 @@ def test_pfb_rfi_mode2_both_streams_bit_exact(oracle, nsets):
     assert (ref_kur != ref_raw).any()
 
 
-def test_pfb_three_sets_resident_input_history_ordering(oracle):
+def test_pfb_three_sets_resident_input_history_ordering(oracle, fuse):
     """Three buffer sets with the input already on the device (no staging between the pb_process calls, as in
     bench.py): batch 0's history kernel runs on the main stream, batch 1's kurtosis pass and PFB weights on the
     kurtosis stream without waiting for batch 0's channeliser -- only ev_hist orders the weights of batch 1's first
@@ -314,7 +323,7 @@ def test_pfb_three_sets_resident_input_history_ordering(oracle):
     assert np.array_equal(np.concatenate(kur), ref_kur), "excised-stream codes differ"
 
 
-def test_pfb_fullsize_two_segments_mode2_bit_exact(oracle):
+def test_pfb_fullsize_two_segments_mode2_bit_exact(oracle, fuse):
     """(c) R = 1024 (the production segment: XCD-aware row mapping, 32-row detect chunks), two segments in one
     call, RFI mode 2, both streams bit-exact against the composed oracle."""
     lp = libpb()
@@ -324,3 +333,58 @@ def test_pfb_fullsize_two_segments_mode2_bit_exact(oracle):
     raw, kur, wts = _run_pipelined(lp, [data], Rf, 2, 2)
     assert np.array_equal(raw[0], ref_raw), "raw-stream codes differ"
     assert np.array_equal(kur[0], ref_kur), "excised-stream codes differ"
+
+
+def _run_many(lp, data, Rr, S, rfi_mode, nant, nsets=2):
+    """batches of S segments through one handle of `nant` antennas (antenna a gets the data rolled by a segments):
+    -> (raw, kur, weights) per antenna, concatenated over the batches"""
+    nb = data.shape[0] // S
+    out = [([], [], []) for _ in range(nant)]
+
+    def collect(h, j):
+        h.select_set(j % nsets)
+        for a in range(nant):
+            o = h.fetch(a, 0, S, raw=rfi_mode != 1, kur=True, weights=True)
+            if rfi_mode != 1:
+                out[a][0].append(o["raw"])
+            out[a][1].append(o["kur"])
+            out[a][2].append(o["weights"])
+
+    with lp.PbHandle(nant=nant, nbit=8, rfi_mode=rfi_mode, taps=4, rows_per_seg=Rr, max_seg=S, nsets=nsets) as h:
+        for k in range(nb):
+            h.select_set(k % nsets)
+            for a in range(nant):
+                d = np.roll(data, a, axis=0)[k * S:(k + 1) * S]
+                for s in range(S):
+                    h.submit_planar(a, s, d[s, 0], d[s, 1])
+            h.process(S)
+            if k >= nsets - 1:
+                collect(h, k - (nsets - 1))
+        for j in range(max(0, nb - (nsets - 1)), nb):
+            collect(h, j)
+    return [tuple(np.concatenate(x) if x else None for x in o) for o in out]
+
+
+@pytest.mark.parametrize("Rr,S,nb,rfi_mode,nant", [(8, 1, 36, 2, 1), (64, 2, 3, 1, 1), (24, 2, 3, 2, 2), (40, 1, 4, 2, 1)])
+def test_pfb_fused_equals_kurtosis_pass(monkeypatch, Rr, S, nb, rfi_mode, nant):
+    """k_channelize_pfb_kur against the three-kernel path (which the tests above pin to the oracle), bit for bit,
+    where the oracle is not needed to tell: 36 launches on two buffer sets (the look-back words' five epoch bits
+    come round, the words are cleared), RFI mode 1 (no raw transform: the masks are needed at once), two antennas in
+    one handle, row counts that allow only one-row strips (24, 40) or eight-row ones (64), rows with code 0 (dropped
+    frames: the row is patched in LDS by the workgroups that read it, the input buffer stays as it was)."""
+    lp = libpb()
+    data = make_input(66, Rr, S * nb)
+    got = {}
+    for level in (1, 2):
+        monkeypatch.setenv("PB_FUSE_KURTOSIS", str(level))
+        got[level] = _run_many(lp, data, Rr, S, rfi_mode, nant)
+    for a in range(nant):
+        for i, what in enumerate(("raw", "kur", "weights")):
+            x, y = got[1][a][i], got[2][a][i]
+            if x is None:
+                assert y is None
+                continue
+            assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), (a, what)
+    assert (got[1][0][1] != 0).any()
+    if rfi_mode == 2:
+        assert (got[1][0][1] != got[1][0][0]).any()       # something was excised

@@ -42,6 +42,15 @@ def test_channelisers_use_no_scratch_and_keep_three_workgroups_per_cu():
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_pfb_channelisers_use_no_scratch_and_keep_three_workgroups_per_cu():
+    u = _usage("k_channelize_pfb.hip")
+    for name in ("k_channelize_pfb7", "k_channelize_pfb_kur"):
+        k = next(v for sym, v in u.items() if name in sym)
+        assert k["ScratchSize"] == 0 and k["NumVgprs"] <= 168 and k["Occupancy"] >= 3, (name, k)
+        assert k["LDSByteSize"] <= 163840 // 3, (name, k)
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
 def test_detect_uses_no_scratch():
     u = _usage("k_detect2.hip")
     assert u and all(v["ScratchSize"] == 0 for v in u.values()), {k: v for k, v in u.items() if v["ScratchSize"]}

@@ -46,8 +46,10 @@ extern "C" int pb_internal_ch_stamps(unsigned long long *out)
 #include "kurtosis_dev.h"
 
 #ifndef CH_ABL
-#define CH_ABL 0      // energy / timing experiments (variant builds only, results invalid): 1 no moments of the statistic,
-                      // 2 no plane stores, 4 no spectrum step, 8 no FFT passes, 16 no staging / unpack of the transforms
+#define CH_ABL 0      // energy / timing experiments (variant builds only, results invalid): 2 no plane stores, 4 no
+                      // spectrum step, 8 no FFT passes, 16 no staging / unpack of the transforms  (1, no moments of the
+                      // statistic, and 32, dword reads for the moments, went with the shared row_block_moments;
+                      // their results are in profiles/r04_notes.md section 8)
 #endif
 struct ChanArgs {
     const uint8_t *in;      // [A][S][2][seg_samples]
@@ -412,98 +414,8 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
     }
     __syncthreads();
     KSTAMP(1);
-    {
-        // moments of the 50 blocks: exactly k_kurtosis_row's reduction (same leaves, same tree, same sharing of the
-        // cross-lane levels between four blocks)
-        auto leaves = [&](int bi, float &r2, float &r4) __attribute__((always_inline)) {
-            const int pol = bi >= 25 ? 1 : 0, blk = bi - 25 * pol;
-            const uint8_t *sb = (const uint8_t *)(pol ? sraw1 : sraw0) + (pol ? off1 : off0) + blk * PB_NKURTO;
-            // Leaves t = lane + 64 i (i = 0..3; i = 3 only for lane < 58) and their partners t + 250.  Two LEAVES share
-            // a packed register -- (t0, t1) and (t2, t3), partners likewise -- so that the pair sums x[t]^2 + x[t+250]^2
-            // of two leaves are one packed add, and level 128 of the tree, (d0 + d2, d1 + d3), another; level 64 adds
-            // the halves.  The same additions on the same operands as one leaf pair per register (which spent a
-            // scalar add per leaf and moment on the pair sum): 30 instead of 44 vector instructions per block.
-            const bool in3 = lane < 250 - 192;
-            const int t3 = in3 ? lane + 192 : 0;
-            f2k uA, uB, uC, uD;
-#if CH_ABL & 32
-            {   // (energy experiment, results invalid: the same conversions fed by two dword reads instead of eight byte reads)
-                const unsigned w0 = ((const unsigned *)((const uint8_t *)(pol ? sraw1 : sraw0) + blk * PB_NKURTO))[lane];
-                const unsigned w1 = ((const unsigned *)((const uint8_t *)(pol ? sraw1 : sraw0) + blk * PB_NKURTO))[lane + 62];
-                uA.x = (float)(w0 & 0xff); uA.y = (float)((w0 >> 8) & 0xff); uB.x = (float)(w1 & 0xff); uB.y = (float)((w1 >> 8) & 0xff);
-                uC.x = (float)((w0 >> 16) & 0xff); uC.y = (float)(w0 >> 24); uD.x = (float)((w1 >> 16) & 0xff); uD.y = (float)(w1 >> 24);
-                (void)sb; (void)t3;
-            }
-#else
-            uA.x = (float)sb[lane];
-            uA.y = (float)sb[lane + 64];
-            uB.x = (float)sb[lane + 250];
-            uB.y = (float)sb[lane + 314];
-            uC.x = (float)sb[lane + 128];
-            uC.y = (float)sb[t3];
-            uD.x = (float)sb[lane + 378];
-            uD.y = (float)sb[t3 + 250];
-#endif
-            const f2k k128 = {0.0078125f, 0.0078125f}, m1 = {-1.0f, -1.0f};
-            const f2k xA = __builtin_elementwise_fma(uA, k128, m1), xB = __builtin_elementwise_fma(uB, k128, m1);
-            const f2k xC = __builtin_elementwise_fma(uC, k128, m1), xD = __builtin_elementwise_fma(uD, k128, m1);
-            const f2k aA = xA * xA, aB = xB * xB, aC = xC * xC, aD = xD * xD;
-            const f2k qA = aA * aA, qB = aB * aB, qC = aC * aC, qD = aD * aD;
-            const f2k e2ab = aA + aB, e4ab = qA + qB;        // (d[0], d[1])
-            f2k e2cd = aC + aD, e4cd = qC + qD;              // (d[2], d[3])
-            e2cd.y = in3 ? e2cd.y : 0.f;
-            e4cd.y = in3 ? e4cd.y : 0.f;
-            const f2k l2 = e2ab + e2cd, l4 = e4ab + e4cd;    // (d0 + d2, d1 + d3)
-            r2 = l2.x + l2.y;
-            r4 = l4.x + l4.y;
-        };
-        const int bi0 = wave * 12 + min(wave, 2), bi1 = (CH_ABL & 1) ? bi0 : bi0 + (wave < 2 ? 13 : 12);
-        int bi = bi0;
-        if (CH_ABL & 1) { if (tid < 50) { s2[tid] = 8.7f; s4[tid] = 0.45f; } }
-        for (; bi + 4 <= bi1; bi += 4) {
-            float a2, a4, b2, b4, c2, c4, e2, e4;
-            leaves(bi, a2, a4);
-            leaves(bi + 1, b2, b4);
-            leaves(bi + 2, c2, c4);
-            leaves(bi + 3, e2, e4);
-            float ab2 = fold32(a2, b2), ab4 = fold32(a4, b4), ce2 = fold32(c2, e2), ce4 = fold32(c4, e4);
-            float q2 = fold16(ab2, ce2), q4 = fold16(ab4, ce4);
-            q2 = add_row_shl<8>(q2);
-            q4 = add_row_shl<8>(q4);
-            q2 = add_row_shl<4>(q2);
-            q4 = add_row_shl<4>(q4);
-            q2 = add_row_shl<2>(q2);
-            q4 = add_row_shl<2>(q4);
-            q2 = add_row_shl<1>(q2);
-            q4 = add_row_shl<1>(q4);
-            if ((lane & 15) == 0) {
-                const int rowi = lane >> 4;                            // 0: A, 1: C, 2: B, 3: E
-                const int dst = bi + ((rowi & 1) << 1) + (rowi >> 1);
-                s2[dst] = q2;
-                s4[dst] = q4;
-            }
-        }
-        for (; bi < bi1; ++bi) {
-            float r2, r4;
-            leaves(bi, r2, r4);
-            r2 = add_down32(r2);
-            r4 = add_down32(r4);
-            r2 = add_down16(r2);
-            r4 = add_down16(r4);
-            r2 = add_row_shl<8>(r2);
-            r4 = add_row_shl<8>(r4);
-            r2 = add_row_shl<4>(r2);
-            r4 = add_row_shl<4>(r4);
-            r2 = add_row_shl<2>(r2);
-            r4 = add_row_shl<2>(r4);
-            r2 = add_row_shl<1>(r2);
-            r4 = add_row_shl<1>(r4);
-            if (lane == 0) {
-                s2[bi] = r2;
-                s4[bi] = r4;
-            }
-        }
-    }
+    // moments of the 50 blocks: k_kurtosis_row's reduction (kurtosis_dev.h)
+    row_block_moments((const uint8_t *)sraw0 + off0, (const uint8_t *)sraw1 + off1, wave, lane, s2, s4);
     __syncthreads();
     KSTAMP(2);
     // The flags are the business of ONE wave: lanes 0..49 decide their block's flag (no cube root, kurtosis_dev.h), a

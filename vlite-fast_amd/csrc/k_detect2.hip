@@ -638,7 +638,7 @@ hipError_t launch_detect_pow(pb_handle *h, int nseg, bool fine_grained)
     // starts straight behind the previous one), two otherwise (measured both ways, see the comment on DEPTH)
     static const int depth_env = getenv("PB_DETECT_DEPTH") ? atoi(getenv("PB_DETECT_DEPTH")) : 0;   // 2 / 3: timing experiments
     const bool deep = depth_env ? depth_env == 3
-                                : (D2_DEPTH_OVERLAPPED == 3 && pb_fused_kurtosis(h) && h->sets.size() >= 2 && h->A == 1);
+                                : (D2_DEPTH_OVERLAPPED == 3 && pb_fused_kurtosis(h) && h->cfg.taps == 1 && h->sets.size() >= 2 && h->A == 1);
     if (h->R % 32 == 0) {
         if (deep) launch_all<32, 3>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
         else launch_all<32, 2>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);

@@ -88,94 +88,8 @@ __global__ __launch_bounds__(256, 6) void k_kurtosis_row(
     __syncthreads();
     KU_STAMP(1);
 
-    // Each wave reduces 12 or 13 consecutive blocks (of the row's 2 x 25).  Leaves t = lane + 64 i hold
-    // (x[t]^2, x[t+250]^2), the pair side by side in packed-f32 instructions; the halving tree's levels 128 and
-    // 64 are additions in registers, 32..1 go across the wave: d[t] += d[t+s].  Four blocks share the
-    // cross-lane levels: one v_permlane32_swap + add folds the upper half of block A and of block B at once
-    // (A ends in lanes 0..31, B in 32..63), one v_permlane16_swap + add does level 16 of four blocks (one per
-    // 16-lane row), and the DPP levels 8..1 work inside rows anyway -- the same additions, on the same
-    // operands, as one block at a time (20 cross-lane instructions per four blocks instead of 120; the
-    // kernel is bound by vector issue in this loop).
-    auto leaves = [&](int bi, float &r2, float &r4) __attribute__((always_inline)) {
-        const int pol = bi >= 25 ? 1 : 0, blk = bi - 25 * pol;
-        const uint8_t *sb = (const uint8_t *)(sraw[pol]) + (pol ? off1 : off0) + blk * PB_NKURTO;
-        // Leaves t = lane + 64 i (i = 0..3; i = 3 only for lane < 58) and their partners t + 250.  Two LEAVES share
-        // a packed register -- (t0, t1) and (t2, t3), partners likewise -- so that the pair sums x[t]^2 + x[t+250]^2
-        // of two leaves are one packed add, and level 128 of the tree, (d0 + d2, d1 + d3), another; level 64 adds
-        // the halves.  The same additions on the same operands as one leaf pair per register (which spent a
-        // scalar add per leaf and moment on the pair sum): 30 instead of 44 vector instructions per block.
-        const bool in3 = lane < 250 - 192;
-        const int t3 = in3 ? lane + 192 : 0;
-        f2k uA, uB, uC, uD;
-        uA.x = (float)sb[lane];
-        uA.y = (float)sb[lane + 64];
-        uB.x = (float)sb[lane + 250];
-        uB.y = (float)sb[lane + 314];
-        uC.x = (float)sb[lane + 128];
-        uC.y = (float)sb[t3];
-        uD.x = (float)sb[lane + 378];
-        uD.y = (float)sb[t3 + 250];
-        const f2k k128 = {0.0078125f, 0.0078125f}, m1 = {-1.0f, -1.0f};
-        const f2k xA = __builtin_elementwise_fma(uA, k128, m1), xB = __builtin_elementwise_fma(uB, k128, m1);
-        const f2k xC = __builtin_elementwise_fma(uC, k128, m1), xD = __builtin_elementwise_fma(uD, k128, m1);
-        const f2k aA = xA * xA, aB = xB * xB, aC = xC * xC, aD = xD * xD;
-        const f2k qA = aA * aA, qB = aB * aB, qC = aC * aC, qD = aD * aD;
-        const f2k e2ab = aA + aB, e4ab = qA + qB;        // (d[0], d[1])
-        f2k e2cd = aC + aD, e4cd = qC + qD;              // (d[2], d[3])
-        e2cd.y = in3 ? e2cd.y : 0.f;
-        e4cd.y = in3 ? e4cd.y : 0.f;
-        const f2k l2 = e2ab + e2cd, l4 = e4ab + e4cd;    // (d0 + d2, d1 + d3)
-        r2 = l2.x + l2.y;
-        r4 = l4.x + l4.y;
-    };
-    // 13, 13, 12, 12 blocks
-    const int bi0 = wave * 12 + min(wave, 2), bi1 = bi0 + (wave < 2 ? 13 : 12);
-    int bi = bi0;
-    for (; bi + 4 <= bi1; bi += 4) {
-        float a2, a4, b2, b4, c2, c4, e2, e4;
-        leaves(bi, a2, a4);
-        leaves(bi + 1, b2, b4);
-        leaves(bi + 2, c2, c4);
-        leaves(bi + 3, e2, e4);
-        // level 32: x' = (x lanes 0..31, y lanes 0..31), y' = (x lanes 32..63, y lanes 32..63)
-        float ab2 = fold32(a2, b2), ab4 = fold32(a4, b4), ce2 = fold32(c2, e2), ce4 = fold32(c4, e4);
-        // level 16: rows (A, C, B, E)
-        float q2 = fold16(ab2, ce2), q4 = fold16(ab4, ce4);
-        q2 = add_row_shl<8>(q2);
-        q4 = add_row_shl<8>(q4);
-        q2 = add_row_shl<4>(q2);
-        q4 = add_row_shl<4>(q4);
-        q2 = add_row_shl<2>(q2);
-        q4 = add_row_shl<2>(q4);
-        q2 = add_row_shl<1>(q2);
-        q4 = add_row_shl<1>(q4);
-        if ((lane & 15) == 0) {
-            const int rowi = lane >> 4;                            // 0: A, 1: C, 2: B, 3: E
-            const int dst = bi + ((rowi & 1) << 1) + (rowi >> 1);
-            s2[dst] = q2;
-            s4[dst] = q4;
-        }
-    }
-    for (; bi < bi1; ++bi) {
-        float r2, r4;
-        leaves(bi, r2, r4);
-        r2 = add_down32(r2);
-        r4 = add_down32(r4);
-        r2 = add_down16(r2);
-        r4 = add_down16(r4);
-        r2 = add_row_shl<8>(r2);
-        r4 = add_row_shl<8>(r4);
-        r2 = add_row_shl<4>(r2);
-        r4 = add_row_shl<4>(r4);
-        r2 = add_row_shl<2>(r2);
-        r4 = add_row_shl<2>(r4);
-        r2 = add_row_shl<1>(r2);
-        r4 = add_row_shl<1>(r4);
-        if (lane == 0) {
-            s2[bi] = r2;
-            s4[bi] = r4;
-        }
-    }
+    // moments of the 2 x 25 blocks: 13, 13, 12, 12 consecutive blocks per wave (kurtosis_dev.h)
+    row_block_moments((const uint8_t *)sraw[0] + off0, (const uint8_t *)sraw[1] + off1, wave, lane, s2, s4);
     __syncthreads();
     KU_STAMP(2);
     const size_t b0 = (size_t)grow * PB_BLK_PER_FFT;   // first block index of this row (per pol)

@@ -125,3 +125,96 @@ template <int S> __device__ __forceinline__ float add_row_shl(float r)
     return r + __int_as_float(t);
 }
 
+
+// Moments of ONE 500-sample block at sb (patched codes, in LDS): this lane's share of sum x^2 and sum x^4 before the
+// cross-lane levels.  Leaves t = lane + 64 i (i = 0..3; i = 3 only for lane < 58) and their partners t + 250: two
+// LEAVES share a packed register -- (t0, t1) and (t2, t3), partners likewise -- so that the pair sums
+// x[t]^2 + x[t+250]^2 of two leaves are one packed add, and level 128 of the halving tree, (d0 + d2, d1 + d3),
+// another; level 64 adds the halves (kurtosis, src/pb_kernels.cu:60-94: the same additions on the same operands).
+__device__ __forceinline__ void block_leaves(const uint8_t *sb, int lane, float &r2, float &r4)
+{
+    const bool in3 = lane < 250 - 192;
+    const int t3 = in3 ? lane + 192 : 0;
+    f2k uA, uB, uC, uD;
+    uA.x = (float)sb[lane];
+    uA.y = (float)sb[lane + 64];
+    uB.x = (float)sb[lane + 250];
+    uB.y = (float)sb[lane + 314];
+    uC.x = (float)sb[lane + 128];
+    uC.y = (float)sb[t3];
+    uD.x = (float)sb[lane + 378];
+    uD.y = (float)sb[t3 + 250];
+    const f2k k128 = {0.0078125f, 0.0078125f}, m1 = {-1.0f, -1.0f};
+    const f2k xA = __builtin_elementwise_fma(uA, k128, m1), xB = __builtin_elementwise_fma(uB, k128, m1);
+    const f2k xC = __builtin_elementwise_fma(uC, k128, m1), xD = __builtin_elementwise_fma(uD, k128, m1);
+    const f2k aA = xA * xA, aB = xB * xB, aC = xC * xC, aD = xD * xD;
+    const f2k qA = aA * aA, qB = aB * aB, qC = aC * aC, qD = aD * aD;
+    const f2k e2ab = aA + aB, e4ab = qA + qB;        // (d[0], d[1])
+    f2k e2cd = aC + aD, e4cd = qC + qD;              // (d[2], d[3])
+    e2cd.y = in3 ? e2cd.y : 0.f;
+    e4cd.y = in3 ? e4cd.y : 0.f;
+    const f2k l2 = e2ab + e2cd, l4 = e4ab + e4cd;    // (d0 + d2, d1 + d3)
+    r2 = l2.x + l2.y;
+    r4 = l4.x + l4.y;
+}
+
+// Moments of a row's 2 x 25 blocks (pol 0's 12500 patched bytes at p0, pol 1's at p1, both in LDS) by the four
+// waves of a workgroup: s2[bi], s4[bi] = sum x^2, sum x^4 of block bi (bi < 25: pol 0).  Each wave reduces 13, 13,
+// 12, 12 consecutive blocks; four blocks share the cross-lane levels of the tree (one v_permlane32_swap + add folds
+// the upper halves of two blocks at once, one v_permlane16_swap + add does level 16 of four, the DPP levels 8..1
+// work inside 16-lane rows anyway): 20 cross-lane instructions per four blocks instead of 120.  The caller puts a
+// barrier before reading s2 / s4.
+__device__ __forceinline__ void row_block_moments(const uint8_t *p0, const uint8_t *p1, int wave, int lane,
+                                                  float *s2, float *s4)
+{
+    auto at = [&](int bi) __attribute__((always_inline)) {
+        return bi >= 25 ? p1 + (bi - 25) * PB_NKURTO : p0 + bi * PB_NKURTO;
+    };
+    const int bi0 = wave * 12 + min(wave, 2), bi1 = bi0 + (wave < 2 ? 13 : 12);
+    int bi = bi0;
+    for (; bi + 4 <= bi1; bi += 4) {
+        float a2, a4, b2, b4, c2, c4, e2, e4;
+        block_leaves(at(bi), lane, a2, a4);
+        block_leaves(at(bi + 1), lane, b2, b4);
+        block_leaves(at(bi + 2), lane, c2, c4);
+        block_leaves(at(bi + 3), lane, e2, e4);
+        // level 32: x' = (x lanes 0..31, y lanes 0..31), y' = (x lanes 32..63, y lanes 32..63)
+        float ab2 = fold32(a2, b2), ab4 = fold32(a4, b4), ce2 = fold32(c2, e2), ce4 = fold32(c4, e4);
+        // level 16: rows (A, C, B, E)
+        float q2 = fold16(ab2, ce2), q4 = fold16(ab4, ce4);
+        q2 = add_row_shl<8>(q2);
+        q4 = add_row_shl<8>(q4);
+        q2 = add_row_shl<4>(q2);
+        q4 = add_row_shl<4>(q4);
+        q2 = add_row_shl<2>(q2);
+        q4 = add_row_shl<2>(q4);
+        q2 = add_row_shl<1>(q2);
+        q4 = add_row_shl<1>(q4);
+        if ((lane & 15) == 0) {
+            const int rowi = lane >> 4;                            // 0: A, 1: C, 2: B, 3: E
+            const int dst = bi + ((rowi & 1) << 1) + (rowi >> 1);
+            s2[dst] = q2;
+            s4[dst] = q4;
+        }
+    }
+    for (; bi < bi1; ++bi) {
+        float r2, r4;
+        block_leaves(at(bi), lane, r2, r4);
+        r2 = add_down32(r2);
+        r4 = add_down32(r4);
+        r2 = add_down16(r2);
+        r4 = add_down16(r4);
+        r2 = add_row_shl<8>(r2);
+        r4 = add_row_shl<8>(r4);
+        r2 = add_row_shl<4>(r2);
+        r4 = add_row_shl<4>(r4);
+        r2 = add_row_shl<2>(r2);
+        r4 = add_row_shl<2>(r4);
+        r2 = add_row_shl<1>(r2);
+        r4 = add_row_shl<1>(r4);
+        if (lane == 0) {
+            s2[bi] = r2;
+            s4[bi] = r4;
+        }
+    }
+}

@@ -42,8 +42,11 @@ extern "C" const char *pb_version(void) { return "pb_hip 0.1 (gfx950)"; }
 
 bool pb_fused_kurtosis(const pb_handle *h)
 {
-    static const int allow = getenv("PB_FUSE_KURTOSIS") ? atoi(getenv("PB_FUSE_KURTOSIS")) : 1;
-    return allow && h->cfg.fft_backend == PB_FFT_LDS && h->cfg.taps == 1 && h->cfg.rfi_mode != 0 && !h->cfg.debug_keep;
+    // h->fuse (PB_FUSE_KURTOSIS when the handle was created): 0 never, 1 the rectangular window only (the default:
+    // for taps = 4 the fused kernel is bit-exact and SLOWER than kurtosis pass + channeliser, profiles/r04_notes.md
+    // section 10), 2 taps = 4 as well
+    if (h->fuse < (h->cfg.taps == 1 ? 1 : 2)) return false;
+    return h->cfg.fft_backend == PB_FFT_LDS && h->cfg.rfi_mode != 0 && !h->cfg.debug_keep;
 }
 
 bool pb_fine_grained(const pb_handle *h)
@@ -54,7 +57,7 @@ bool pb_fine_grained(const pb_handle *h)
     // their places, and a detect that trickles in over 0.3 ms no longer has a step's slack to finish in.
     static const int allow = PB_FG && (getenv("PB_FINE_GRAINED") ? atoi(getenv("PB_FINE_GRAINED")) : 1);
     static const int overlap_detect = getenv("PB_OVERLAP_DETECT") ? atoi(getenv("PB_OVERLAP_DETECT")) : 1;
-    return allow && overlap_detect && pb_fused_kurtosis(h) && h->sets.size() >= 2 && h->A == 1 && h->S <= PB_FG_MAXSEG &&
+    return allow && overlap_detect && pb_fused_kurtosis(h) && h->cfg.taps == 1 && h->sets.size() >= 2 && h->A == 1 && h->S <= PB_FG_MAXSEG &&
            h->d_ready != nullptr;
 }
 
@@ -313,6 +316,7 @@ static int create_impl(pb_handle *h)
     h->sets.resize(c.nsets);
     h->chunk_rows = (R % 32 == 0) ? 32 : 8;
     h->ready_epoch.assign(c.nsets, std::vector<uint32_t>(S, 0u));
+    h->pfb_epoch.assign(c.nsets, 0u);
     {
         // (mapped page-locked word: the device writes it only when a detect workgroup gives up waiting for a row)
         HIPCHK(h, hipHostMalloc((void **)&h->d_fg_error, sizeof(uint32_t), hipHostMallocMapped));
@@ -441,6 +445,7 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
 
     pb_handle *h = new pb_handle();
     h->cfg = c;
+    h->fuse = getenv("PB_FUSE_KURTOSIS") ? atoi(getenv("PB_FUSE_KURTOSIS")) : 1;
     h->R = c.rows_per_seg;
     h->S = c.max_seg;
     h->A = c.nant;
@@ -1011,6 +1016,12 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         static const int skip = getenv("PB_SKIP") ? atoi(getenv("PB_SKIP")) : 0;
         if (!(skip & 1))
             HIPCHK(h, h->cfg.taps == 4 ? launch_channelize_pfb(h, nseg, inject_now) : launch_channelize(h, nseg, inject_now));
+        if (h->cfg.taps == 4 && pb_fused_kurtosis(h)) {
+            // The fused channeliser has written the batch's flags: keep its last three rows and their flags for the next
+            // batch in the history slot this batch did not read.  Same stream as every channeliser: behind the previous
+            // one (which read that slot) and in front of the next (which will).
+            HIPCHK(h, launch_pfb_history(h, nseg));
+        }
         t.stop();
     }
     HIPCHK(h, hipEventRecord(h->ev_fftdone, h->stream));
@@ -1101,7 +1112,7 @@ extern "C" int pb_select_set(pb_handle *h, int set)
 static int check_fine_grained(pb_handle *h)
 {
     if (h->d_fg_error && *(volatile uint32_t *)h->d_fg_error)
-        return fail(h, PB_ESTATE, "detect gave up waiting for rows of its batch's channeliser (row-ready counters): results invalid");
+        return fail(h, PB_ESTATE, "a workgroup gave up waiting for another's rows (detect's row-ready counters, or the taps = 4 channeliser's look-back): results invalid");
     return PB_OK;
 }
 

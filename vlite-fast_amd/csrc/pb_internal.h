@@ -101,6 +101,8 @@ struct pb_handle {
     };
     std::vector<std::vector<uint32_t>> ready_epoch;   // [set][seg] batches that segment slot of the set has seen
     int chunk_rows;                                    // detect's chunk: 32 rows, 8 when R is not a multiple of 32
+    int fuse;                                          // PB_FUSE_KURTOSIS at pb_create (pb_fused_kurtosis)
+    std::vector<uint32_t> pfb_epoch;                   // per buffer set: launches of k_channelize_pfb_kur on it, 1..31 (the look-back words' epoch)
     uint32_t *d_fg_error;                              // a detect workgroup gave up waiting for a row (must stay 0)
     std::vector<BufSet> sets;
     int cur_set;
