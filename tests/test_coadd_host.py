@@ -13,6 +13,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 import synth
@@ -188,3 +189,45 @@ def test_coadd_host_world2_files_and_sum(tmp_path):
     # every rank submitted its own antennas only, second by second in lockstep
     sub0 = eval((tmp_path / "rc0").read_text().split(" ", 1)[1])
     assert [(c[2], c[3]) for c in sub0] == [(0, 3600), (1, 3600), (0, 3601), (1, 3601)]
+
+
+def test_incoherent_coadd_source_switch():
+    """IncoherentCoadd(source=...): "planes" queues pb_coadd_local, "codes" pb_coadd_local_codes (and never the
+    coadd-target shortcut, which hands detect's fp32 plane to the reduce); anything else is refused.  One process,
+    no process group: the local sum and the root's requantisation only."""
+    coadd = importlib.import_module("vlite-fast_amd.coadd")
+
+    class H(FakeCoaddHandle):
+        def coadd_local_codes(self, nseg, ptr, accumulate=False):
+            # each code as the centre of its cell, (q - 127) * 0.02957 (include/pb_hip.h)
+            m = self._mem(ptr, nseg * TRIM)
+            s = np.zeros(nseg * TRIM, np.float32)
+            for a in range(self.nant):
+                q = self.done[self.cur_set][a][1, :nseg * TRIM].astype(np.float64)
+                s = s + ((q - 127.0) * 0.02957).astype(np.float32)
+            m[:] = s
+            self.calls.append(("coadd_local_codes", self.cur_set))
+
+        def set_coadd_target(self, ptr):
+            self.calls.append(("target", ptr))
+
+    rng = np.random.default_rng(5)
+    for source in ("planes", "codes"):
+        h = H(2)
+        h.cfg.fft_backend = 0
+        h.done[0] = [rng.integers(0, 256, (2, SEG * TRIM), dtype=np.uint8) for _ in range(2)]
+        c = coadd.IncoherentCoadd(h, 2, "cpu", backend="gloo", source=source)
+        assert not c.use_target
+        out = c.step(SEG)
+        assert out is not None and out.size == SEG * TRIM
+        names = [x[0] for x in h.calls]
+        assert ("coadd_local_codes" in names) == (source == "codes") and ("coadd_local" in names) == (source == "planes")
+        c.close()
+    h1 = H(1)
+    h1.cfg.fft_backend = 0
+    assert coadd.IncoherentCoadd(h1, 4, "cpu", backend="gloo").use_target            # one antenna, planes: the shortcut
+    h1 = H(1)
+    h1.cfg.fft_backend = 0
+    assert not coadd.IncoherentCoadd(h1, 4, "cpu", backend="gloo", source="codes").use_target
+    with pytest.raises(ValueError):
+        coadd.IncoherentCoadd(H(1), 1, "cpu", source="sum")
