@@ -677,6 +677,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # (dmabuf IPC: the only kind this pool's host driver supports; must be in the environment before HIP starts)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     # the CPU baseline forks a process pool: before torch / HIP are initialised in this process
