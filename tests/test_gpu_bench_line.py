@@ -51,6 +51,9 @@ def test_bench_line_fields_and_consistency():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Msamp/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] / c["value"] > 50                                # (reported only; sanity of units)
+    hp = c["hot_path"]                                                 # the oracle's K1-K11 chain on the same workload, one core
+    assert "error" not in hp, hp
+    assert hp["kind"] == "port" and hp["cores"] == 1 and 1 < hp["value"] < c["value_1core"] * 2 and "configs[1]" in hp["sample"]
 
 
 def test_bench_two_kernel_path_still_reports_kurtosis_stage():
