@@ -6,5 +6,6 @@ d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print(d['ms_per_st
 for v in 2 1; do echo "== PB_FUSE_KURTOSIS=$v"; PB_FUSE_KURTOSIS=$v run; done
 echo "== unfused, kurtosis launch left out once the flags exist (PB_SKIP=4)"; PB_FUSE_KURTOSIS=1 PB_SKIP=4 run
 export PB_FUSE_KURTOSIS=2
-echo "== fused, own flags from the previous launch's bytes: no staging of the own row, no moments (PB_PFB_DBG=4)"; PB_PFB_DBG=4 run
-echo "== fused, moments left out only (PB_PFB_DBG=6)"; PB_PFB_DBG=6 run
+echo "== fused, own flags from the previous launch's bytes: no staging of the own row, no moments (PB_PFB_DBG=1)"; PB_PFB_DBG=1 run
+echo "== fused, no look-back wait: predecessors' words by ordinary loads (PB_PFB_DBG=2)"; PB_PFB_DBG=2 run
+echo "== fused, both (PB_PFB_DBG=3)"; PB_PFB_DBG=3 run

@@ -64,8 +64,9 @@ struct PfbArgs {
     const float *tapE;       // [101] window energy per (tap, block), and their sum
     uint32_t *gave_up;       // mapped host word: a look-back wait ran out (must stay 0)
     unsigned epoch;          // 1..31, this launch's
-    int dbg;                 // PB_PFB_DBG=1 (timing experiments, results invalid): no staging of the own row and no moments,
-                             // the row's flags taken from the bytes an earlier launch left for the same input
+    int dbg;                 // PB_PFB_DBG (timing experiments, results invalid): 1 no staging of the own row and no moments,
+                             // the row's flags taken from the bytes an earlier launch left for the same input; 2 the
+                             // predecessors' words by ordinary loads, whatever their epoch (no look-back wait)
     int strip_shift;         // rows -> workgroups: strips of 1 << strip_shift rows per XCD (-1: row = blockIdx.x)
 };
 #ifndef PFB_SPIN_LIMIT
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb_kur(PfbArgs a)
     const size_t rb0 = (size_t)ant * a.in_ant_stride + (size_t)seg * 2 * a.seg_samples + (size_t)row * PB_NFFT;
     const size_t rb1 = rb0 + a.seg_samples;
     const unsigned off0 = (unsigned)(rb0 & 15), off1 = (unsigned)(rb1 & 15);
-    if (!a.dbg) {
+    if (!(a.dbg & 1)) {
         const uint4 *s0 = (const uint4 *)(a.in + (rb0 - off0)), *s1 = (const uint4 *)(a.in + (rb1 - off1));
         const bool h0 = tid + 768 < (int)((off0 + PB_NFFT + 15) >> 4), h1 = tid + 768 < (int)((off1 + PB_NFFT + 15) >> 4);
         const uint4 a0 = s0[tid], a1 = s0[tid + 256], a2 = s0[tid + 512];
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb_kur(PfbArgs a)
     }
     const DagConsts dc = *a.dag;
     __syncthreads();
-    if (!a.dbg) row_block_moments(lds + off0, lds + PFB_ROW_LDS + off1, wave, lane, smom, smom + 50);
+    if (!(a.dbg & 1)) row_block_moments(lds + off0, lds + PFB_ROW_LDS + off1, wave, lane, smom, smom + 50);
     else if (tid < 100) smom[tid] = tid < 50 ? 8.7f : 0.45f;
     __syncthreads();
 
@@ -409,14 +410,15 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb_kur(PfbArgs a)
     const size_t wi = (size_t)ant * a.wrow_ant_stride;
     if (wave == 0) {
         if (lane < 3 && grow - 3 + lane >= 0)
-            lb = __hip_atomic_load(a.info + wi + (grow - 3 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            lb = (a.dbg & 2) ? a.info[wi + (grow - 3 + lane)]      // (timing: an ordinary cached load of whatever is there)
+                             : __hip_atomic_load(a.info + wi + (grow - 3 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         bool f = false;
         if (lane < 50) {
             const float p = smom[lane] / PB_NKURTO;
             const float k = smom[50 + lane] / PB_NKURTO / (p * p);
             f = dag_flag(k, dc);
         }
-        if (a.dbg) f = lane < 25 && a.flags_out[(size_t)ant * a.flags_ant_stride + (size_t)grow * PB_BLK_PER_FFT + lane] != 0;
+        if (a.dbg & 1) f = lane < 25 && a.flags_out[(size_t)ant * a.flags_ant_stride + (size_t)grow * PB_BLK_PER_FFT + lane] != 0;
         // bit b = block b flagged in pol 0 or pol 1 (compute_dagostino's max over pols, src/pb_kernels.cu:109-134)
         const unsigned long long bal = __ballot(f);
         const uint32_t m = (uint32_t)((bal | (bal >> 25)) & 0x1ffffffull);
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb_kur(PfbArgs a)
             if (rr >= 0) {
                 unsigned v = lb;
                 int spins = 0;
-                while ((v >> 27) != a.epoch) {
+                while ((v >> 27) != a.epoch && !(a.dbg & 2)) {
                     __builtin_amdgcn_s_sleep(4);
                     v = __hip_atomic_load(a.info + wi + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     if (++spins > PFB_SPIN_LIMIT ||
@@ -649,7 +651,7 @@ hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now)
     a.gave_up = h->d_fg_error;
     a.epoch = 0;
     static const int pfb_dbg = getenv("PB_PFB_DBG") ? atoi(getenv("PB_PFB_DBG")) : 0;
-    a.dbg = pfb_dbg && h->processed > 0;      // (the set must hold the flags of the same input)
+    a.dbg = h->processed > 0 ? pfb_dbg : 0;   // (the set must hold the flags of the same input)
     a.strip_shift = -1;
     if (pb_fused_kurtosis(h)) {
         // one workgroup per row (both pols): it computes the row's flags itself and looks back for its predecessors'
