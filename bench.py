@@ -174,11 +174,11 @@ def measured_traffic(stage, args, taps, A=1):
     import glob
     if args.backend != "lds" or args.rfi_mode != 2 or args.seg_per_step != 10 or A != 1 or args.rfi_frac:
         return None
-    # (the library's rule, pb_fused_kurtosis: level 1 fuses the rectangular window only, 2 also taps = 4)
-    fused = args.rfi_mode != 0 and int(os.environ.get("PB_FUSE_KURTOSIS", "1") or 0) >= (1 if taps == 1 else 2)
+    # (the library's rule, pb_fused_kurtosis: the rectangular-window channeliser flags its own rows unless
+    #  PB_FUSE_KURTOSIS=0; taps = 4 always runs kurtosis pass + weights + k_channelize_pfb)
+    fused = args.rfi_mode != 0 and taps == 1 and int(os.environ.get("PB_FUSE_KURTOSIS", "1") or 0) >= 1
     names = {"kurtosis": "k_kurtosis_row",
-             "channelize": ("k_channelize_pfb_kur" if fused else "k_channelize_pfb") if taps == 4
-                           else ("k_channelize_kur" if fused else "k_channelize"),
+             "channelize": "k_channelize_pfb" if taps == 4 else ("k_channelize_kur" if fused else "k_channelize"),
              "detect": "k_detect2"}
     want = names.get(stage)
     best = None
@@ -389,7 +389,7 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
         # batch k+1; no host synchronisation inside a step.  One antenna per GPU: detect writes the plane to be
         # reduced straight into the leg's buffer of the batch's set and the local sum needs no kernel.
         cmod = importlib.import_module("vlite-fast_amd.coadd")
-        leg = cmod.IncoherentCoadd(h, nant_total, dev, root=0, backend=args.dist_backend,
+        leg = cmod.IncoherentCoadd(h, nant_total, dev, root=0, backend=args.dist_backend, order=args.coadd_order,
                                    parts=int(os.environ.get("PB_COADD_PARTS", "7")))     # (parts: timing experiments)
     nstream_out = (0, 1) if args.rfi_mode == 2 else ((0,) if args.rfi_mode == 0 else (1,))
     state = {"k": 0, "sink": 0, "coadds": 0}
@@ -622,6 +622,9 @@ def build_parser():
                     help="buffer sets (1 = no batch pipelining; 3 = the host collects batch k - 2 after queuing batch "
                          "k, so that its wait for a copy-out never keeps the next batch from being queued)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal)")
+    ap.add_argument("--coadd-order", choices=["tree", "fast"], default="tree",
+                    help="N > 1: tree (default) = the defined order of the fp32 additions (local tree, gather to rank 0, "
+                         "root tree: the same coadded bytes on any number of GPUs); fast = one RCCL reduce(SUM)")
     ap.add_argument("--share-gpus", action="store_true",
                     help="rehearsal only: let more ranks than there are GPUs run (ranks wrap onto the cards); "
                          "without it a run with fewer GPUs than ranks fails")
@@ -763,7 +766,8 @@ def main():
                                    "(10 x 100-ms segments, 2048 x 12500-pt FFT rows each), RFI mode %d, "
                                    "%d-bit out, taps=%d, %s FFT" % (which, A, args.rfi_mode, args.nbit, args.taps, args.backend),
                        "antennas": nant_total, "antennas_per_gpu": A, "segments_per_step": S,
-                       "parallelism": "antenna-per-GPU" + ("+rccl-reduce-coadd" if world > 1 else "")},
+                       "parallelism": "antenna-per-GPU" + (("+rccl-gather-tree-coadd" if args.coadd_order == "tree"
+                                                                        else "+rccl-reduce-coadd") if world > 1 else "")},
             "msamp_per_antenna": round(msamp / nant_total, 1),
             "x_realtime_per_antenna": round(msamp / nant_total / 128.0, 1),
             "x_realtime_per_antenna_cold": round(msamp / nant_total / 128.0 * r["ms_per_step"] / r["ms_per_step_cold"], 1),
@@ -776,6 +780,12 @@ def main():
             out["gpus_visible"] = ndev
             out["per_rank"] = r.get("per_rank")
             out["reduce_leg"] = r.get("reduce_leg")
+            out["coadd_order"] = {"order": args.coadd_order,
+                                  "meaning": ("antennas split by index parity, recursively (DESIGN.md section 6): every rank's "
+                                              "node by pb_coadd_local_tree, one fp32 plane per rank gathered to rank 0, "
+                                              "pb_coadd_tree there; bytes independent of the number of GPUs")
+                                  if args.coadd_order == "tree" else
+                                  "left-to-right local sums, one RCCL reduce(SUM): association left to the collective"}
             # one rank per GPU, all of them in the group: anything else is not the run the line claims to be
             if not args.share_gpus:
                 assert out["rccl_ranks"] == out["n_gpus"] == args.gpus and ndev >= world, (out["rccl_ranks"], out["n_gpus"], ndev)
@@ -789,9 +799,11 @@ def main():
                                "per_rank": c3.get("per_rank"), "reduce_leg": c3.get("reduce_leg"),
                                "product": "vlite-fast_amd/coadd_host.py runs this leg (coadd.IncoherentCoadd) on antenna "
                                           "dumps / rings and writes the one station-99 .fil",
-                               "note": "BASELINE configs[3] (16 antennas on 8 GPUs): %d antennas here, 2 per GPU, fp32 reduce "
-                                       "of the locally pre-summed planes to rank 0, which requantises the coadded "
-                                       "second" % c3["nant_total"]}
+                               "note": "BASELINE configs[3] (16 antennas on 8 GPUs): %d antennas here, 2 per GPU, the fp32 "
+                                       "planes summed in the order \"%s\" (%s) on rank 0, which requantises the "
+                                       "coadded second" % (c3["nant_total"], args.coadd_order,
+                                                           "local tree, gather, root tree" if args.coadd_order == "tree"
+                                                           else "local sum, one reduce")}
         if world == 1:
             try:
                 out["roofline"]["alone"] = alone_record(torch, lp, args, dev, local, args.taps)

@@ -201,6 +201,22 @@ int pb_coadd_local_codes(pb_handle *h, int nseg, float *d_sum, int accumulate);
  * plane); pb_coadd_local(h, nseg, that pointer, 0) then only orders the coadd stream behind detect, and
  * pb_coadd_release -- called after the host has queued the collective (and pb_coadd_finish on the root) on the
  * coadd stream -- tells the library that the buffer may be overwritten by the set's next batch. */
+/* The incoherent sum in a DEFINED order, so that the coadded bytes do not depend on how the antennas are spread over
+ * GPUs or on a collective's internal order (the reference's coadder, scripts/start_coadd:16,20-58,
+ * is an external MPI program whose arithmetic is not in the repository).  The order: antennas split by the parity of
+ * their index, recursively -- S(o, s) = S(o, 2s) + S(o + s, 2s), a single antenna's plane at the leaves, coadded =
+ * S(0, 1).  With the leaves listed left to right that is T_1(x) = x, T_n(x_0..x_{n-1}) = T_ceil(n/2)(x_0..) +
+ * T_floor(n/2)(x_ceil(n/2)..), which is what these two calls evaluate, fp32, element by element:
+ *   pb_coadd_local_tree: d_dst[seg][ave_floats] = T_n over the fp32 planes (kur stream; raw if rfi_mode 0) of this
+ *     handle's antennas ant_order[0..n) of the selected set's batch -- one rank's node of the tree.  Ordered against
+ *     detect and the set's next batch like pb_coadd_local.  Needs keep_ave.
+ *   pb_coadd_tree: d_dst[0..nfloat) = T_n over n caller-owned device planes d_leaves[0..n) (the root: the ranks'
+ *     partial sums as gathered), on the coadd stream.  d_dst must not be one of the leaves unless n = 1.
+ * n <= PB_COADD_MAX_LEAVES; planes 16-byte aligned, nfloat a multiple of 4.  Which plane is which leaf is the host's
+ * business (vlite-fast_amd/coadd.py: tree_order); pb_coadd_finish(d_dst) follows on the root. */
+#define PB_COADD_MAX_LEAVES 32
+int pb_coadd_local_tree(pb_handle *h, int nseg, const int32_t *ant_order, int n, float *d_dst);
+int pb_coadd_tree(pb_handle *h, const float *const *d_leaves, int n, float *d_dst, size_t nfloat);
 int pb_set_coadd_target(pb_handle *h, float *d_sum);
 int pb_coadd_release(pb_handle *h);
 /* Run pb_coadd_local / pb_coadd_finish (and so the collective the host queues between them) on

@@ -78,3 +78,19 @@ def header_symbols():
     txt = open(os.path.join(ROOT, "include", "pb_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(pb_[a-z0-9_]+)\s*\(", txt)))
+
+
+def parity_sum(planes, o=0, s=1):
+    """The defined order of the incoherent sum, straight from its definition:
+    S(o, s) = planes[o] when {o, o+s, ...} holds one antenna, else S(o, 2s) + S(o+s, 2s); coadded = S(0, 1)."""
+    if o + s >= len(planes):
+        return planes[o]
+    return parity_sum(planes, o, 2 * s) + parity_sum(planes, o + s, 2 * s)
+
+
+def count_tree(leaves):
+    """T_n of include/pb_hip.h: what pb_coadd_tree evaluates over leaves listed in tree order."""
+    n = len(leaves)
+    if n == 1:
+        return leaves[0]
+    return count_tree(leaves[:(n + 1) // 2]) + count_tree(leaves[(n + 1) // 2:])

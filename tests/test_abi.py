@@ -56,3 +56,34 @@ def test_product_does_not_import_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")) or fn == "Makefile":
                 txt = open(os.path.join(dp, fn)).read()
                 assert not bad.search(txt), fn
+
+
+def test_shipped_library_holds_no_result_invalidating_switch():
+    """Switches whose effect is "results invalid" (PB_SKIP: a kernel left out; PB_PFB_DBG: flags from stale bytes)
+    exist in experiment builds only (`make exp` / tools/build_variants.sh, selected with PB_LIBPATH): the shipped
+    library -- and the native host program -- do not even contain the variables' names, so no environment can make a
+    production host write garbage.  Every getenv the library does make is of a switch that leaves results unchanged
+    (scheduling and timing choices, each covered by tests/test_gpu_schedules.py)."""
+    import re
+    csrc = os.path.join(ROOT, "vlite-fast_amd", "csrc")
+    forbidden = (b"PB_SKIP", b"PB_PFB_DBG", b"CH_ABL", b"FFT_ABL", b"D2_ABL")
+    for fn in ("libpb_hip.so", "libpb_hip_fg.so", "process_baseband"):
+        path = os.path.join(csrc, fn)
+        if not os.path.exists(path):
+            assert fn != "libpb_hip.so"
+            continue
+        blob = open(path, "rb").read()
+        for name in forbidden:
+            assert name not in blob, "%s contains %s" % (fn, name.decode())
+    # and the sources read the environment only through names on this list
+    allowed = {"PB_LEAN_LDS", "PB_COPY_DMA", "PB_COPY_WGS", "PB_DETECT_DEPTH", "PB_FINE_GRAINED", "PB_OVERLAP_DETECT",
+               "PB_DET_CUS", "PB_DET_PRIO", "PB_FUSE_KURTOSIS", "PB_KUR_EARLY", "PB_SKIP"}
+    seen = set()
+    for fn in os.listdir(csrc):
+        if fn.endswith((".hip", ".h")):
+            seen |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(os.path.join(csrc, fn)).read()))
+    assert seen <= allowed, seen - allowed
+    txt = open(os.path.join(csrc, "pb_api.hip")).read()
+    i = txt.index('getenv("PB_SKIP")')
+    assert "#if PB_EXPERIMENTS" in txt[max(0, i - 200):i]       # the one PB_SKIP read sits behind the build switch
+    assert txt.count('getenv("PB_SKIP")') == 2                   # (both on that one line)

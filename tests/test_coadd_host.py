@@ -1,9 +1,12 @@
-"""The coadder host (vlite-fast_amd/coadd_host.py, BASELINE configs[3]) without a GPU: two ranks under gloo, the
-device replaced by a stand-in whose outputs are pure functions of the samples it was given, so that every byte of
-every file can be predicted.  Under test: antenna a -> rank a mod world, streams aligned on their VDIF seconds (one
-antenna starts a second early, one ends a second early), every antenna's own .fil / _kur.fil, the per-second
-incoherent-sum leg through coadd.IncoherentCoadd (local sum -> dist.reduce -> the root's requantisation, collected
-one second late), the single station-99 file with its SIGPROC header and the coadded ring.
+"""The coadder host (vlite-fast_amd/coadd_host.py, BASELINE configs[3]) without a GPU: 2 / 3 / 5 / 8 ranks under gloo
+-- 8 ranks x 16 antennas is configs[3]'s real shape -- the device replaced by a stand-in whose outputs are pure
+functions of the samples it was given, so that every byte of every file can be predicted.  Under test: antenna a ->
+rank a mod world (uneven shards included), streams aligned on their VDIF seconds (one antenna starts a second early,
+one ends a second early), every antenna's own .fil / _kur.fil, the per-second incoherent-sum leg through
+coadd.IncoherentCoadd (local tree -> dist.gather -> the root's tree and requantisation, collected one second late),
+the single station-99 file with its SIGPROC header and the coadded ring.  The coadded bytes must equal the DEFINED
+order of the fp32 additions (antennas split by index parity, recursively: DESIGN.md section 6) -- written down here
+from that definition, not from the plan coadd.py derives from it -- and so be the SAME bytes for every world size.
 Reference: scripts/start_coadd:16,20-58 (one coadder rank per antenna ring), src/process_baseband.cu:272-285
 (station-99 name), :1416-1422 (coadd ring feed)."""
 import argparse
@@ -17,14 +20,18 @@ import pytest
 import torch.multiprocessing as mp
 
 import synth
+from helpers import count_tree, parity_sum
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R, SEG = 8, 10
 NSEC_SAMP = R * SEG * 12500
 FPS = NSEC_SAMP // 5000
 TRIM = 2 * R * 4096 // 16              # 8-bit, npol 1: bytes per segment == fp32 plane floats per segment
-NANT = 4
-STATIONS = [7, 12, 15, 21]
+STATIONS = [7 + 3 * a for a in range(16)]
+
+
+def _plane(codes):
+    return (codes.astype(np.float32) - np.float32(128)) * np.float32(1.1)
 
 
 def _mods():
@@ -33,8 +40,10 @@ def _mods():
 
 class FakeCoaddHandle(object):
     """Duck-typed PbHandle(keep_ave=True) with `nant` local antennas: host deframe; codes = the staged samples
-    (pol 0 -> raw stream, pol 1 -> excised stream); fp32 plane = float(excised codes) - 128; pb_coadd_local /
-    pb_coadd_finish act on the caller's buffer through its address, like the library."""
+    (pol 0 -> raw stream, pol 1 -> excised stream); fp32 plane = _plane(excised codes), values with full mantissas so
+    that fp32 sums of them depend on the association; the "requantisation" keeps the LOW mantissa byte of the scaled
+    sum, so that one ulp anywhere changes the file; pb_coadd_local / pb_coadd_tree / pb_coadd_finish act on the
+    caller's buffers through their addresses, like the library."""
 
     def __init__(self, nant, nsets=2):
         self.nant, self.nsets, self.trim, self.max_seg, self.ave_per_seg = nant, nsets, TRIM, SEG, TRIM
@@ -80,15 +89,25 @@ class FakeCoaddHandle(object):
         m = self._mem(ptr, nseg * TRIM)
         s = np.zeros(nseg * TRIM, np.float32)
         for a in range(self.nant):
-            s = s + (self.done[self.cur_set][a][1, :nseg * TRIM].astype(np.float32) - np.float32(128))
+            s = s + _plane(self.done[self.cur_set][a][1, :nseg * TRIM])
         m[:] = s
         self.calls.append(("coadd_local", self.cur_set))
 
+    def coadd_local_tree(self, nseg, order, ptr):
+        m = self._mem(ptr, nseg * TRIM)
+        m[:] = count_tree([_plane(self.done[self.cur_set][a][1, :nseg * TRIM]) for a in order])
+        self.calls.append(("coadd_local_tree", self.cur_set, tuple(order)))
+
+    def coadd_tree(self, leaf_ptrs, dst, nfloat):
+        v = count_tree([self._mem(p, nfloat).copy() for p in leaf_ptrs])
+        self._mem(dst, nfloat)[:] = v
+        self.calls.append(("coadd_tree", len(leaf_ptrs)))
+
     def coadd_finish(self, nseg, ptr, nant_total, blocking=True):
         m = self._mem(ptr, nseg * TRIM)
-        v = m * np.float32(1.0 / np.sqrt(float(nant_total))) + np.float32(128)
+        v = m * np.float32(1.0 / np.sqrt(float(nant_total)))
         slot = self.co_last ^ 1
-        self.co[slot] = np.clip(v, 0, 255).astype(np.uint8)
+        self.co[slot] = (v.view(np.uint32) & np.uint32(0xFF)).astype(np.uint8)
         self.co_last = slot
 
     def coadd_view(self, nseg, age=0):
@@ -121,7 +140,7 @@ def _stream(ant):
     return hdr, body
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, NANT, order):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -130,7 +149,8 @@ def _worker(rank, world, port, tmp):
     vdif, sigproc, dada, coadd, host = _mods()
     args = host.build_parser().parse_args(["--replay"] + ["unused"] * NANT + ["-b", "8", "-r", "2", "-w", "2", "--datadir", tmp,
                                            "--logdir", os.path.join(tmp, "logs"), "--rows-per-seg", str(R),
-                                           "--dist-backend", "gloo", "--out-sink", os.path.join(tmp, "co_ring.bin")])
+                                           "--dist-backend", "gloo", "--coadd-order", order,
+                                           "--out-sink", os.path.join(tmp, "co_ring.bin")])
     mine = coadd.antennas_of_rank(NANT, rank, world)
     rings = {}
     for a in mine:
@@ -141,54 +161,138 @@ def _worker(rank, world, port, tmp):
         r.end_of_data()
         rings[a] = r
     h = FakeCoaddHandle(len(mine), nsets=2)
-    co = coadd.IncoherentCoadd(h, NANT, torch.device("cpu"), root=0, backend="gloo")
+    co = coadd.IncoherentCoadd(h, NANT, torch.device("cpu"), root=0, backend="gloo", order=order)
     rc = host.run(args, rank=rank, world=world, local=0, rings=rings, handle=h, dist=dist, device=torch.device("cpu"), coadd=co)
     with open(os.path.join(tmp, "rc%d" % rank), "w") as f:
-        f.write("%d %s" % (rc, [c for c in h.calls if c[0] == "submit"]))
+        f.write("%d %s" % (rc, [c for c in h.calls if c[0] in ("submit", "coadd_tree")]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_coadd_host_world2_files_and_sum(tmp_path):
+def _run_world(tmp_path, world, NANT, order):
     os.environ["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"),
                                                 os.environ.get("PYTHONPATH", "")])
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
     ctx = mp.get_context("spawn")
-    port = 29900 + os.getpid() % 2000
+    port = 29900 + (os.getpid() * 7 + world * 13 + NANT) % 2000
     tmp = str(tmp_path)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, tmp)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tmp, NANT, order)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=180)
+        p.join(timeout=300)
         assert p.exitcode == 0
+    for r in range(world):
+        assert (tmp_path / ("rc%d" % r)).read_text().startswith("0 ")
+
+
+def _expected(NANT, secs):
+    """per-antenna file bodies and fp32 planes over the coadded seconds"""
+    raws, kurs, planes = [], [], []
+    for a in range(NANT):
+        raws.append(b"".join(_second(a, s)[0][:SEG * TRIM].tobytes() for s in secs))
+        kurs.append(b"".join(_second(a, s)[1][:SEG * TRIM].tobytes() for s in secs))
+        planes.append(_plane(np.concatenate([_second(a, s)[1][:SEG * TRIM] for s in secs])))
+    return raws, kurs, planes
+
+
+def _quantise(tot, NANT):
+    v = tot * np.float32(1.0 / np.sqrt(float(NANT)))
+    return (v.view(np.uint32) & np.uint32(0xFF)).astype(np.uint8).tobytes()
+
+
+@pytest.mark.parametrize("world,NANT", [(8, 16), (3, 7), (5, 11), (4, 6)])
+def test_coadd_host_tree_order_files_and_sum(tmp_path, world, NANT):
+    """(8, 16): two antennas per rank, configs[3]; (3, 7) and (5, 16): worlds that are not powers of two ship every
+    antenna's plane, shards 3/2/2 and 3/2/2/2/2; (4, 6): a power of two with uneven shards 2/2/1/1"""
+    _run_world(tmp_path, world, NANT, "tree")
     vdif, sigproc, dada, coadd, host = _mods()
-    for r in range(2):
-        txt = (tmp_path / ("rc%d" % r)).read_text()
-        assert txt.startswith("0 ")
     # the sum covers seconds 3600 and 3601: antenna 1's early second is skipped, antenna 2's stream ends with 3602,
     # which -- being its last -- is dropped
     secs = [3600, 3601]
     dmjd = 57570 + 3600 / 86400.
-    planes = []
+    raws, kurs, planes = _expected(NANT, secs)
     for a in range(NANT):
         hdr = sigproc.sigproc_header(STATIONS[a], 0.8718, -0.72452, "B0833-45", dmjd, 1, 8)
-        raw = b"".join(_second(a, s)[0][:SEG * TRIM].tobytes() for s in secs)
-        kur = b"".join(_second(a, s)[1][:SEG * TRIM].tobytes() for s in secs)
-        assert (tmp_path / ("20160701_010000_muos_ea%02d.fil" % STATIONS[a])).read_bytes() == hdr + raw, a
-        assert (tmp_path / ("20160701_010000_muos_ea%02d_kur.fil" % STATIONS[a])).read_bytes() == hdr + kur, a
-        planes.append(np.concatenate([_second(a, s)[1][:SEG * TRIM] for s in secs]).astype(np.float32) - np.float32(128))
-    # rank 0 holds antennas 0 and 2, rank 1 antennas 1 and 3; fp32 sums in that order, 1 / sqrt(4)
-    tot = ((np.float32(0) + planes[0]) + planes[2]) + ((np.float32(0) + planes[1]) + planes[3])
-    want = np.clip(tot * np.float32(0.5) + np.float32(128), 0, 255).astype(np.uint8).tobytes()
+        assert (tmp_path / ("20160701_010000_muos_ea%02d.fil" % STATIONS[a])).read_bytes() == hdr + raws[a], a
+        assert (tmp_path / ("20160701_010000_muos_ea%02d_kur.fil" % STATIONS[a])).read_bytes() == hdr + kurs[a], a
+    want = _quantise(parity_sum(planes), NANT)
     co_hdr = sigproc.sigproc_header(99, 0.8718, -0.72452, "B0833-45", dmjd, 1, 8)
     assert (tmp_path / "20160701_010000_muos_ea99_kur.fil").read_bytes() == co_hdr + want
     ring = (tmp_path / "co_ring.bin").read_bytes()
     rh = vdif.ascii_header_parse(ring[:4096])
     assert rh["STATIONID"] == "99" and rh["SIGPROC_FILE"].endswith("_muos_ea99_kur.fil") and rh["NBIT"] == "8"
     assert ring[4096:] == want
-    # every rank submitted its own antennas only, second by second in lockstep
-    sub0 = eval((tmp_path / "rc0").read_text().split(" ", 1)[1])
-    assert [(c[2], c[3]) for c in sub0] == [(0, 3600), (1, 3600), (0, 3601), (1, 3601)]
+    # every rank submitted its own antennas only, second by second in lockstep; the root summed one plane per rank
+    # (power-of-two world) or one per antenna
+    calls0 = eval((tmp_path / "rc0").read_text().split(" ", 1)[1])
+    n0 = len(coadd.antennas_of_rank(NANT, 0, world))
+    assert [(c[2], c[3]) for c in calls0 if c[0] == "submit"] == [(i, s) for s in secs for i in range(n0)]
+    assert [c[1] for c in calls0 if c[0] == "coadd_tree"] == [world if coadd.is_pow2(world) else NANT] * len(secs)
+    # the order really matters for these data (else the test could not tell a wrong plan from a right one)
+    naive = np.float32(0)
+    for pl in planes:
+        naive = naive + pl
+    if NANT > 2:
+        assert _quantise(naive, NANT) != want
+
+
+def test_tree_plan_matches_definition():
+    """coadd.tree_order + T_n (the device's shape) == S(0, 1) for every antenna count, and the two-level plan of a
+    power-of-two world (local trees, then the ranks' partial sums in tree order) is the same association"""
+    coadd = _mods()[3]
+    rng = np.random.default_rng(11)
+    for N in range(1, 33):
+        planes = [(rng.standard_normal(257) * 10.0 ** rng.integers(-3, 4)).astype(np.float32) for _ in range(N)]
+        want = parity_sum(planes)
+        assert np.array_equal(count_tree([planes[a] for a in coadd.tree_order(range(N))]), want), N
+        for W in (1, 2, 4, 8, 16, 32):
+            if W > N:
+                continue
+            parts = []
+            for r in range(W):
+                mine = coadd.antennas_of_rank(N, r, W)
+                parts.append(count_tree([planes[mine[j]] for j in coadd.tree_order(range(len(mine)))]))
+            assert np.array_equal(count_tree([parts[r] for r in coadd.tree_order(range(W))]), want), (N, W)
+    assert coadd.tree_order(range(8)) == [0, 4, 2, 6, 1, 5, 3, 7] and coadd.tree_order(range(5)) == [0, 4, 2, 1, 3]
+
+
+def test_coadd_host_fast_order_world2(tmp_path):
+    """`--coadd-order fast`: left-to-right local sums and ONE dist.reduce; with two ranks the association is known"""
+    NANT = 4
+    _run_world(tmp_path, 2, NANT, "fast")
+    sigproc = _mods()[1]
+    raws, kurs, planes = _expected(NANT, [3600, 3601])
+    # rank 0 holds antennas 0 and 2, rank 1 antennas 1 and 3; fp32 sums in that order, 1 / sqrt(4)
+    tot = ((np.float32(0) + planes[0]) + planes[2]) + ((np.float32(0) + planes[1]) + planes[3])
+    co_hdr = sigproc.sigproc_header(99, 0.8718, -0.72452, "B0833-45", 57570 + 3600 / 86400., 1, 8)
+    assert (tmp_path / "20160701_010000_muos_ea99_kur.fil").read_bytes() == co_hdr + _quantise(tot, NANT)
+
+
+def test_coadd_host_refuses_colliding_station_ids(tmp_path, monkeypatch):
+    """two streams with one STATIONID would open the same .fil twice: refused (exit 1, nothing coadded) unless -w 0"""
+    vdif, sigproc, dada, coadd, host = _mods()
+    import torch
+    monkeypatch.setattr(sys.modules[__name__], "STATIONS", [7, 7])
+    for wflag, want_rc in (("2", 1), ("0", 0)):
+        d = tmp_path / wflag
+        d.mkdir()
+        args = host.build_parser().parse_args(["--replay", "a", "b", "-b", "8", "-r", "2", "-w", wflag, "--datadir", str(d),
+                                               "--logdir", str(d / "logs"), "--rows-per-seg", str(R), "--dist-backend", "gloo"])
+        rings = {}
+        for a in range(2):
+            hdr, body = _stream(a)
+            r = dada.MemoryRing()
+            r.write_header(hdr)
+            r.write(np.frombuffer(body, np.uint8))
+            r.end_of_data()
+            rings[a] = r
+        h = FakeCoaddHandle(2, nsets=2)
+        co = coadd.IncoherentCoadd(h, 2, torch.device("cpu"), backend="gloo")
+        rc = host.run(args, rank=0, world=1, rings=rings, handle=h, device=torch.device("cpu"), coadd=co)
+        assert rc == want_rc
+        assert (d / "20160701_010000_muos_ea99_kur.fil").exists() == (want_rc == 0)
+        assert not (d / "20160701_010000_muos_ea07.fil").exists()
 
 
 def test_incoherent_coadd_source_switch():
@@ -221,13 +325,23 @@ def test_incoherent_coadd_source_switch():
         out = c.step(SEG)
         assert out is not None and out.size == SEG * TRIM
         names = [x[0] for x in h.calls]
-        assert ("coadd_local_codes" in names) == (source == "codes") and ("coadd_local" in names) == (source == "planes")
+        assert ("coadd_local_codes" in names) == (source == "codes") and ("coadd_local_tree" in names) == (source == "planes")
+        assert "coadd_local" not in names and c.order == ("tree" if source == "planes" else "fast")
         c.close()
     h1 = H(1)
     h1.cfg.fft_backend = 0
-    assert coadd.IncoherentCoadd(h1, 4, "cpu", backend="gloo").use_target            # one antenna, planes: the shortcut
+    assert coadd.IncoherentCoadd(h1, 1, "cpu", backend="gloo").use_target            # one antenna, planes: the shortcut
     h1 = H(1)
     h1.cfg.fft_backend = 0
-    assert not coadd.IncoherentCoadd(h1, 4, "cpu", backend="gloo", source="codes").use_target
+    assert not coadd.IncoherentCoadd(h1, 1, "cpu", backend="gloo", source="codes").use_target
+    with pytest.raises(ValueError):                          # one rank cannot hold 1 of 4 antennas under a mod world
+        coadd.IncoherentCoadd(H(1), 4, "cpu", backend="gloo")
     with pytest.raises(ValueError):
         coadd.IncoherentCoadd(H(1), 1, "cpu", source="sum")
+    with pytest.raises(ValueError):
+        coadd.IncoherentCoadd(H(1), 1, "cpu", order="ring")
+    hf = H(2)
+    hf.done[0] = [rng.integers(0, 256, (2, SEG * TRIM), dtype=np.uint8) for _ in range(2)]
+    cf = coadd.IncoherentCoadd(hf, 2, "cpu", backend="gloo", order="fast")
+    cf.step(SEG)
+    assert "coadd_local" in [x[0] for x in hf.calls]

@@ -1,13 +1,14 @@
-"""BASELINE configs[3] end to end on the GPU: the coadder host (vlite-fast_amd/coadd_host.py) started as TWO ranks
-(`--ranks 2`, gloo rehearsal back end, both ranks on the one GPU this pool hands out), FOUR antenna dumps, two
-antennas per rank batched in one handle -- pb_submit_vdif -> pb_process -> pb_coadd_local -> dist.reduce ->
-pb_coadd_finish on the root -- against the oracle:
+"""BASELINE configs[3] end to end on the GPU: the coadder host (vlite-fast_amd/coadd_host.py) started as 2, 3 or 4
+ranks (`--ranks N`, gloo rehearsal back end, all ranks on the one GPU this pool hands out), up to EIGHT antenna
+dumps, the rank's antennas batched in one handle -- pb_submit_vdif -> pb_process -> pb_coadd_local_tree ->
+dist.gather -> pb_coadd_tree + pb_coadd_finish on the root -- against the oracle:
   * every antenna's own .fil / _kur.fil byte for byte = header + the oracle's codes of that antenna's data;
   * the ONE coadded file `..._ea99_kur.fil` byte for byte = the station-99 SIGPROC header +
-    sel_and_dig_8b( ((ave_kur_0 + ave_kur_2) + (ave_kur_1 + ave_kur_3)) * float(1/sqrt 4) ) of the oracle's fp32
-    excised planes (rank 0 holds antennas 0 and 2, rank 1 antennas 1 and 3; fp32 sums in that order);
+    sel_and_dig( S(0, 1) * float(1/sqrt N) ) of the oracle's fp32 excised planes, S the DEFINED order of the fp32
+    additions (antennas split by index parity, recursively: helpers.parity_sum) -- the same
+    expectation whatever the number of ranks;
   * the coadded ring stand-in carries the same bytes behind a header naming that file.
-(With RCCL the same code runs `dist.reduce` on the device buffers; more than one RCCL rank needs more than one GPU.)
+(With RCCL the same code runs `dist.gather` on the device buffers; more than one RCCL rank needs more than one GPU.)
 Reference: scripts/start_coadd:16,20-58; src/process_baseband.cu:272-285,1416-1422."""
 import importlib
 import os
@@ -17,7 +18,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import make_input, oracle_run
+from helpers import count_tree, make_input, oracle_run, parity_sum
 
 pytestmark = pytest.mark.gpu
 
@@ -27,7 +28,7 @@ sigproc = importlib.import_module("vlite-fast_amd.sigproc")
 
 R, SEG = 8, 10
 NANT = 4
-STATIONS = [3, 8, 11, 27]
+STATIONS = [3, 8, 11, 27, 30, 41, 52, 63]
 
 
 def _dump(path, data, station):
@@ -41,11 +42,14 @@ def _dump(path, data, station):
             f.write(vdif.frame_block(p0, p1, 3600 + s, 33, station).tobytes())
 
 
-@pytest.mark.parametrize("nbit,NANT", [(8, 4), (2, 3)])
-def test_two_ranks_four_antennas_coadded_fil_is_byte_exact(tmp_path, oracle, nbit, NANT):
-    """(8 bit, 4 antennas: two per rank, scale exactly 1/2; 2 bit, 3 antennas: ranks hold {0, 2} and {1}, scale
-    float(1 / sqrt 3))"""
-    nsec = 4                                         # -> 3 s out (the last second of every stream is dropped)
+@pytest.mark.parametrize("nbit,NANT,ranks,order", [(8, 8, 4, "tree"), (8, 4, 2, "tree"), (2, 3, 2, "tree"), (8, 5, 3, "tree"),
+                                                   (8, 4, 2, "fast")])
+def test_ranks_antennas_coadded_fil_is_byte_exact(tmp_path, oracle, nbit, NANT, ranks, order):
+    """(4 ranks x 8 antennas: two per rank, configs[3]'s shape at half size; 2 ranks x 4: scale exactly 1/2; 2 bit,
+    3 antennas: ranks hold {0, 2} and {1}, scale float(1 / sqrt 3); 3 ranks x 5 antennas: not a power of two, every
+    antenna's plane goes to the root; "fast": one dist.reduce of left-to-right local sums, whose two-rank association
+    is known)"""
+    nsec = 3 if NANT > 4 else 4                      # -> 2 / 3 s out (the last second of every stream is dropped)
     data = [make_input(80 + a, R, nsec * SEG, rfi=a != 1, dropped=a == 2) for a in range(NANT)]
     dumps = []
     for a in range(NANT):
@@ -53,8 +57,8 @@ def test_two_ranks_four_antennas_coadded_fil_is_byte_exact(tmp_path, oracle, nbi
         _dump(p, data[a], STATIONS[a])
         dumps.append(p)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, os.path.join(ROOT, "vlite-fast_amd", "coadd_host.py"), "--ranks", "2", "--dist-backend", "gloo",
-           "--share-gpus", "--replay"] + dumps + ["-b", str(nbit), "-r", "2", "-w", "2", "--datadir", str(tmp_path),
+    cmd = [sys.executable, os.path.join(ROOT, "vlite-fast_amd", "coadd_host.py"), "--ranks", str(ranks), "--dist-backend", "gloo",
+           "--share-gpus", "--coadd-order", order, "--replay"] + dumps + ["-b", str(nbit), "-r", "2", "-w", "2", "--datadir", str(tmp_path),
            "--logdir", str(tmp_path / "logs"), "--rows-per-seg", str(R), "--out-sink", str(tmp_path / "co_ring.bin")]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
@@ -71,10 +75,17 @@ def test_two_ranks_four_antennas_coadded_fil_is_byte_exact(tmp_path, oracle, nbi
         planes.append([x.ave_kur for x in res])
     scale = np.float32(1.0 / np.sqrt(float(NANT)))
     want = b""
+    naive = b""
     for s in range(nseg):
-        part1 = (np.float32(0) + planes[1][s]) + (planes[3][s] if NANT > 3 else np.float32(0))
-        tot = ((np.float32(0) + planes[0][s]) + planes[2][s]) + part1
+        if order == "tree":
+            tot = parity_sum([planes[a][s] for a in range(NANT)])
+        else:
+            tot = ((np.float32(0) + planes[0][s]) + planes[2][s]) + ((np.float32(0) + planes[1][s]) + planes[3][s])
         want += oracle.sel_and_dig(tot * scale, R, npol=1, nbit=nbit).tobytes()
+        lr = np.float32(0)
+        for a in range(NANT):
+            lr = lr + planes[a][s]
+        naive += oracle.sel_and_dig(lr * scale, R, npol=1, nbit=nbit).tobytes()
     co_hdr = sigproc.sigproc_header(99, 0.8718, -0.72452, "B0833-45", dmjd, 1, nbit)
     co = (tmp_path / "20160701_010000_muos_ea99_kur.fil").read_bytes()
     assert co[:len(co_hdr)] == co_hdr
@@ -87,6 +98,8 @@ def test_two_ranks_four_antennas_coadded_fil_is_byte_exact(tmp_path, oracle, nbi
     assert ring[4096:] == want
     # the coadded stream is not any single antenna's
     assert want != b"".join(oracle.sel_and_dig(planes[0][s], R, nbit=nbit).tobytes() for s in range(nseg))
+    log = "".join(open(os.path.join(str(tmp_path / "logs"), f)).read() for f in os.listdir(str(tmp_path / "logs")))
+    assert 'order "%s"' % order in log
 
 
 def test_single_rank_coadd_of_two_antennas_equals_two_rank_sum(tmp_path, oracle):
@@ -105,7 +118,7 @@ def test_single_rank_coadd_of_two_antennas_equals_two_rank_sum(tmp_path, oracle)
     nseg = (nsec - 1) * SEG
     planes = [[x.ave_kur for x in oracle_run(oracle, data[a][:nseg], R)[0]] for a in range(2)]
     scale = np.float32(1.0 / np.sqrt(2.0))
-    want = b"".join(oracle.sel_and_dig(((np.float32(0) + planes[0][s]) + planes[1][s]) * scale, R).tobytes() for s in range(nseg))
+    want = b"".join(oracle.sel_and_dig(parity_sum([planes[0][s], planes[1][s]]) * scale, R).tobytes() for s in range(nseg))
     co_hdr = sigproc.sigproc_header(99, 0.8718, -0.72452, "B0833-45", 57570 + 3600 / 86400., 1, 8)
     assert (tmp_path / "20160701_010000_muos_ea99_kur.fil").read_bytes() == co_hdr + want
     assert not (tmp_path / ("20160701_010000_muos_ea%02d.fil" % STATIONS[0])).exists()      # -w 0
@@ -131,7 +144,7 @@ def test_single_rank_coadd_other_modes(tmp_path, oracle, rfi_mode, npol):
     res = [oracle_run(oracle, data[a][:nseg], R, rfi_mode=rfi_mode, npol=npol, nbit=8)[0] for a in range(2)]
     key = "ave_raw" if rfi_mode == 0 else "ave_kur"
     scale = np.float32(1.0 / np.sqrt(2.0))
-    want = b"".join(oracle.sel_and_dig(((np.float32(0) + getattr(res[0][s], key)) + getattr(res[1][s], key)) * scale, R, npol=npol).tobytes()
+    want = b"".join(oracle.sel_and_dig(parity_sum([getattr(res[0][s], key), getattr(res[1][s], key)]) * scale, R, npol=npol).tobytes()
                     for s in range(nseg))
     co_hdr = sigproc.sigproc_header(99, 0.8718, -0.72452, "B0833-45", 57570 + 3600 / 86400., npol, 8)
     name = "20160701_010000_muos_ea99%s.fil" % ("" if rfi_mode == 0 else "_kur")
@@ -165,7 +178,7 @@ def test_fullsize_coadd_two_antennas_one_second(tmp_path, oracle):
     nseg = (nsec - 1) * SEG
     res = [oracle_run(oracle, data[a][:nseg], Rf)[0] for a in range(2)]
     scale = np.float32(1.0 / np.sqrt(2.0))
-    want = b"".join(oracle.sel_and_dig(((np.float32(0) + res[0][s].ave_kur) + res[1][s].ave_kur) * scale, Rf).tobytes() for s in range(nseg))
+    want = b"".join(oracle.sel_and_dig(parity_sum([res[0][s].ave_kur, res[1][s].ave_kur]) * scale, Rf).tobytes() for s in range(nseg))
     dmjd = 57570 + 3600 / 86400.
     co_hdr = sigproc.sigproc_header(99, 0.8718, -0.72452, "B0833-45", dmjd, 1, 8)
     assert (tmp_path / "20160701_010000_muos_ea99_kur.fil").read_bytes() == co_hdr + want

@@ -255,17 +255,8 @@ def test_pfb_pipelined_two_sets_mode0_bit_exact(oracle):
     assert np.array_equal(np.concatenate(raw), ref)
 
 
-@pytest.fixture(params=[1, 2], ids=["kurtosis-pass", "fused"])
-def fuse(request, monkeypatch):
-    """PB_FUSE_KURTOSIS as pb_create reads it: 1 = kurtosis pass + weights kernel + k_channelize_pfb (the default for
-    taps = 4), 2 = k_channelize_pfb_kur, the channeliser that flags its own rows and looks back for its predecessors'
-    (bit-exact, measured slower: opt-in)."""
-    monkeypatch.setenv("PB_FUSE_KURTOSIS", str(request.param))
-    return request.param
-
-
 @pytest.mark.parametrize("nsets", [1, 2, 3])
-def test_pfb_rfi_mode2_both_streams_bit_exact(oracle, nsets, fuse):
+def test_pfb_rfi_mode2_both_streams_bit_exact(oracle, nsets):
     """(b) RFI mode 2 as benchmarked: RFI bursts, a row with every block flagged (weight 0 for four output rows'
     window share), a strongly flagged stretch, a dropped frame, three batches (flags of the carried rows are used
     by the next batch).  Raw AND excised codes bit-exact, weights bit-exact.  nsets = 3: the kurtosis pass of batch k + 1
@@ -292,7 +283,7 @@ def test_pfb_rfi_mode2_both_streams_bit_exact(oracle, nsets, fuse):
     assert (ref_kur != ref_raw).any()
 
 
-def test_pfb_three_sets_resident_input_history_ordering(oracle, fuse):
+def test_pfb_three_sets_resident_input_history_ordering(oracle):
     """Three buffer sets with the input already on the device (no staging between the pb_process calls, as in
     bench.py): batch 0's history kernel runs on the main stream, batch 1's kurtosis pass and PFB weights on the
     kurtosis stream without waiting for batch 0's channeliser -- only ev_hist orders the weights of batch 1's first
@@ -323,7 +314,7 @@ def test_pfb_three_sets_resident_input_history_ordering(oracle, fuse):
     assert np.array_equal(np.concatenate(kur), ref_kur), "excised-stream codes differ"
 
 
-def test_pfb_fullsize_two_segments_mode2_bit_exact(oracle, fuse):
+def test_pfb_fullsize_two_segments_mode2_bit_exact(oracle):
     """(c) R = 1024 (the production segment: XCD-aware row mapping, 32-row detect chunks), two segments in one
     call, RFI mode 2, both streams bit-exact against the composed oracle."""
     lp = libpb()
@@ -365,26 +356,23 @@ def _run_many(lp, data, Rr, S, rfi_mode, nant, nsets=2):
     return [tuple(np.concatenate(x) if x else None for x in o) for o in out]
 
 
-@pytest.mark.parametrize("Rr,S,nb,rfi_mode,nant", [(8, 1, 36, 2, 1), (64, 2, 3, 1, 1), (24, 2, 3, 2, 2), (40, 1, 4, 2, 1)])
-def test_pfb_fused_equals_kurtosis_pass(monkeypatch, Rr, S, nb, rfi_mode, nant):
-    """k_channelize_pfb_kur against the three-kernel path (which the tests above pin to the oracle), bit for bit,
-    where the oracle is not needed to tell: 36 launches on two buffer sets (the look-back words' five epoch bits
-    come round, the words are cleared), RFI mode 1 (no raw transform: the masks are needed at once), two antennas in
-    one handle, row counts that allow only one-row strips (24, 40) or eight-row ones (64), rows with code 0 (dropped
-    frames: the row is patched in LDS by the workgroups that read it, the input buffer stays as it was)."""
+@pytest.mark.parametrize("Rr,S,nb,rfi_mode,nant", [(8, 1, 9, 2, 1), (64, 2, 3, 1, 1), (24, 2, 3, 2, 2)])
+def test_pfb_buffer_set_counts_agree(Rr, S, nb, rfi_mode, nant):
+    """The same batches through one, two and three buffer sets (no pipelining; detect beside the next channeliser;
+    the kurtosis pass beside the previous channeliser as well) give the same bytes and weights: RFI mode 1 (no raw
+    transform), two antennas in one handle, a row count that is no multiple of 32 (8-row detect chunks), rows with
+    code 0 (dropped frames).  The one-set results are the ones the tests above pin to the oracle."""
     lp = libpb()
     data = make_input(66, Rr, S * nb)
-    got = {}
-    for level in (1, 2):
-        monkeypatch.setenv("PB_FUSE_KURTOSIS", str(level))
-        got[level] = _run_many(lp, data, Rr, S, rfi_mode, nant)
-    for a in range(nant):
-        for i, what in enumerate(("raw", "kur", "weights")):
-            x, y = got[1][a][i], got[2][a][i]
-            if x is None:
-                assert y is None
-                continue
-            assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), (a, what)
+    got = {n: _run_many(lp, data, Rr, S, rfi_mode, nant, nsets=n) for n in (1, 2, 3)}
+    for n in (2, 3):
+        for a in range(nant):
+            for i, what in enumerate(("raw", "kur", "weights")):
+                x, y = got[1][a][i], got[n][a][i]
+                if x is None:
+                    assert y is None
+                    continue
+                assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), (n, a, what)
     assert (got[1][0][1] != 0).any()
     if rfi_mode == 2:
         assert (got[1][0][1] != got[1][0][0]).any()       # something was excised

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Energy experiment: joules per step of the pipeline (or of one of its kernels: PB_SKIP=1 leaves the channeliser
-out, 2 detect) from amdsmi's energy accumulator, next to time and mean power.  Variant libraries (PB_LIBPATH) with
-parts of a kernel compiled out give the energy of those parts by difference.
+out, 2 detect -- results invalid, so the switch exists only in the experiments build: `make -C vlite-fast_amd/csrc exp`,
+PB_LIBPATH=vlite-fast_amd/csrc/libpb_hip_exp.so) from amdsmi's energy accumulator, next to time and mean power.
+Variant libraries (PB_LIBPATH) with parts of a kernel compiled out give the energy of those parts by difference.
 usage: python tools/energy_probe.py [seconds] [taps]"""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,6 +40,9 @@ def energy():
     e = amdsmi.amdsmi_get_energy_count(g)
     return e["energy_accumulator"] * e["counter_resolution"] * 1e-6      # joules
 
+if os.environ.get("PB_SKIP") and "exp" not in os.path.basename(os.environ.get("PB_LIBPATH", "")):
+    sys.exit("PB_SKIP is read by the experiments build only: make -C vlite-fast_amd/csrc exp; "
+             "PB_LIBPATH=vlite-fast_amd/csrc/libpb_hip_exp.so")
 run(0.5)
 e0 = energy(); k, dt = run(dur); e1 = energy()
 idle0 = energy(); time.sleep(1.0); idle1 = energy()

@@ -1,18 +1,29 @@
-"""Incoherent antenna sum across GPUs: RCCL reduce over xGMI in place of the reference's
-external MPI coadder (`agdadacoadd`, /root/reference/scripts/start_coadd:16,56-58, which is not
-in the reference repository -- its arithmetic is unpinned).
+"""Incoherent antenna sum across GPUs, in place of the reference's external MPI coadder (`agdadacoadd`,
+/root/reference/scripts/start_coadd:16,20-58, one rank per antenna ring under mpirun; it is not in the reference
+repository -- its arithmetic is unpinned).
 
-Partitioning: antennas are independent until the sum, so antenna a lives on rank
-a mod world; each rank pre-sums the fp32 pre-quantisation planes of its own antennas on its GPU
-(pb_coadd_local), ONE reduce(SUM, fp32) per batch brings the partial sums to the root, and the
-root scales by 1/sqrt(N_ant) (the reference's variance-preserving convention,
-src/pb_kernels.cu:522,568,623) and requantises (pb_coadd_finish -> sel_and_dig).
-Only the root needs the result, so a reduce (not an all-reduce) is the right collective: on
-xGMI's point-to-point links a direct-to-root reduce of 7 x 20 MiB per second of data is far
-below one link's bandwidth.
+Partitioning: antennas are independent until the sum, so antenna a lives on rank a mod world.
+What is summed are the fp32 pre-quantisation planes; the root scales by 1/sqrt(N_ant) (the reference's
+variance-preserving convention, src/pb_kernels.cu:522,568,623) and requantises (pb_coadd_finish -> sel_and_dig).
 
-`IncoherentCoadd` is the per-rank driver of that leg; bench.py (N > 1), the coadder host
-(coadd_host.py, BASELINE configs[3]) and the tests all go through it.
+The ORDER of the fp32 additions is defined, so that the coadded bytes are the same on 1, 2, 4, 8 (or any number of)
+GPUs and can be checked against the oracle byte for byte (order="tree", the default):
+
+    S(o, s) = plane of antenna o                    when o + s >= N_ant
+            = S(o, 2 s) + S(o + s, 2 s)             otherwise (even members + odd members of {o, o+s, o+2s, ...})
+    coadded = S(0, 1)
+
+With world a power of two, rank r's antennas {r, r+W, ...} ARE the node S(r, W): the rank evaluates it on its own GPU
+(pb_coadd_local_tree), ONE plane per rank goes to the root (a gather: point-to-point sends, one xGMI hop each, 7 x
+20 MiB per second of data at 8 GPUs -- far below one link's bandwidth), and the root evaluates the top log2 W levels
+over the partial sums in bit-reversed rank order (pb_coadd_tree).  Any other world size ships the antennas' planes
+themselves and the root evaluates the whole tree: same bytes, more traffic.
+order="fast" is one RCCL reduce(SUM, fp32) of the locally pre-summed planes to the root: the association is then the
+collective's (ring / tree by topology and message size) and the bytes are not reproducible across world sizes; kept
+for comparison (`--coadd-order fast`).
+
+`IncoherentCoadd` is the per-rank driver of that leg; bench.py (N > 1), the coadder host (coadd_host.py, BASELINE
+configs[3]) and the tests all go through it.
 """
 import torch
 import torch.distributed as dist
@@ -21,6 +32,20 @@ import torch.distributed as dist
 def antennas_of_rank(nant, rank, world):
     """Antenna indices owned by `rank`: a mod world == rank."""
     return [a for a in range(nant) if a % world == rank]
+
+
+def tree_order(items):
+    """The leaves of S over `items` (a list in index order) from left to right: even positions first, recursively.
+    tree_order(range(8)) = [0, 4, 2, 6, 1, 5, 3, 7] (bit reversal); tree_order(range(5)) = [0, 4, 2, 1, 3].  The
+    device evaluates T_n over leaves listed this way (include/pb_hip.h: pb_coadd_tree)."""
+    items = list(items)
+    if len(items) <= 1:
+        return items
+    return tree_order(items[0::2]) + tree_order(items[1::2])
+
+
+def is_pow2(n):
+    return n >= 1 and (n & (n - 1)) == 0
 
 
 def reduce_to_root(t, root=0, group=None):
@@ -34,18 +59,21 @@ class IncoherentCoadd(object):
     """The incoherent-sum leg of one rank, pipelined behind the batches of a PbHandle.
 
     handle: PbHandle(keep_ave=True, nsets=n) holding this rank's antennas.  The leg has a stream of its own
-    (pb_set_coadd_stream): local sum -> reduce -> the root's requantisation of batch k are ordered on it by the
-    device and run beside the kernels of the batches after it; nothing here synchronises the host except the
-    rehearsal back end ("gloo": the partial sums cross through host memory).
+    (pb_set_coadd_stream): local sum -> gather / reduce -> the root's sum and requantisation of batch k are ordered
+    on it by the device and run beside the kernels of the batches after it; nothing here synchronises the host except
+    the rehearsal back end ("gloo": the partial sums cross through host memory).
 
-    With one local antenna and the in-library FFT the plane to be reduced IS the antenna's plane: detect writes it
-    straight into this object's buffer of the batch's buffer set (pb_set_coadd_target) and the local sum launches
-    nothing.  Otherwise pb_coadd_local sums the rank's antennas into one buffer.
+    order="tree" (default): the defined order of the module docstring -- pb_coadd_local_tree on every rank, a gather
+    of the ranks' planes to the root, pb_coadd_tree there.  order="fast": pb_coadd_local (left to right over the
+    rank's antennas) and one dist.reduce; the bytes then depend on the world size and the collective.
+
+    With one local antenna and the in-library FFT the plane to be shipped IS the antenna's plane: detect writes it
+    straight into this object's buffer of the batch's buffer set (pb_set_coadd_target) and the local step launches
+    nothing.
 
     source="codes": the local sum is taken from the antennas' QUANTISED filterbank bytes (each code stands for the
     centre of its quantiser cell; pb_coadd_local_codes) -- what a coadder fed from the co rings has to work with.
-    The reduce and the root's requantisation are the same.  For like-for-like comparisons; the
-    default sums the fp32 planes.
+    For like-for-like comparisons only: it always takes the "fast" route.
 
     queue(set_index, nseg): call once the batch in that buffer set is known to be complete on the device (its
     filterbank bytes have been fetched), i.e. one step behind the batch itself -- no device-side wait for detect is
@@ -55,24 +83,42 @@ class IncoherentCoadd(object):
     """
 
     def __init__(self, handle, nant_total, device, root=0, backend="nccl", group=None, use_target=None, parts=7,
-                 source="planes"):
+                 source="planes", order="tree"):
         if source not in ("planes", "codes"):
             raise ValueError("source must be 'planes' or 'codes'")
+        if order not in ("tree", "fast"):
+            raise ValueError("order must be 'tree' or 'fast'")
         self.source = source               # "codes": sum the antennas' quantised bytes (pb_coadd_local_codes)
         if source == "codes":
             use_target = False
+            order = "fast"
+        self.order = order
         self.h = handle
         self.nant_total = int(nant_total)
         self.root = root
         self.backend = backend
         self.group = group
-        self.parts = parts                 # timing experiments: 1 local sum, 2 reduce, 4 requantisation
+        self.parts = parts                 # timing experiments: 1 local sum, 2 collective, 4 root sum + requantisation
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        n = handle.max_seg * handle.ave_per_seg
+        if root != 0 and order == "tree":
+            raise ValueError("the tree order is rooted at rank 0")
+        A, W, N = handle.nant, self.world, self.nant_total
+        n = self.n = handle.max_seg * handle.ave_per_seg
+        # what a rank ships: its node of the tree (one plane) when the world is a power of two, otherwise every
+        # antenna's plane (padded to the largest rank's count: a gather moves equal pieces)
+        self.node_per_rank = order == "fast" or is_pow2(W)
+        self.ship = 1 if self.node_per_rank else -(-N // W)
+        if order == "tree":
+            if self.node_per_rank and len(antennas_of_rank(N, self.rank, W)) != A:
+                raise ValueError("rank %d of %d holds %d antennas, the sharding a mod world gives it %d of %d"
+                                 % (self.rank, W, A, len(antennas_of_rank(N, self.rank, W)), N))
+            if max(A if self.node_per_rank else N, W) > 32:
+                raise ValueError("the tree sum takes at most 32 leaves (PB_COADD_MAX_LEAVES)")
+            self.local_order = tree_order(range(A))          # local antenna j is antenna rank + j * world
         if use_target is None:
-            use_target = handle.nant == 1 and handle.cfg.fft_backend == 0
-        self.sums = [torch.zeros(n, dtype=torch.float32, device=device)
+            use_target = A == 1 and handle.cfg.fft_backend == 0
+        self.sums = [torch.zeros(self.ship * n, dtype=torch.float32, device=device)
                      for _ in range(handle.nsets if use_target else 1)]
         self.use_target = bool(use_target)
         if self.use_target:
@@ -80,6 +126,15 @@ class IncoherentCoadd(object):
                 handle.select_set(st)
                 handle.set_coadd_target(self.sums[st].data_ptr())
             handle.select_set(0)
+        self.gath = self.total = self.leaves = None
+        if order == "tree" and W > 1 and self.rank == root:
+            self.gath = torch.zeros(W * self.ship * n, dtype=torch.float32, device=device)
+            self.total = torch.zeros(n, dtype=torch.float32, device=device)
+            g0 = self.gath.data_ptr()
+            if self.node_per_rank:
+                self.leaves = [g0 + 4 * n * r for r in tree_order(range(W))]
+            else:
+                self.leaves = [g0 + 4 * n * ((a % W) * self.ship + a // W) for a in tree_order(range(N))]
         # (a CPU `device` exists for the host-logic tests: a stand-in handle, no stream, gloo)
         self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         handle.sync()
@@ -105,32 +160,58 @@ class IncoherentCoadd(object):
     def buffer(self, set_index):
         return self.sums[set_index] if self.use_target else self.sums[0]
 
+    def _collective(self, ds):
+        """the ranks' planes to the root: dist.gather into self.gath (tree) / dist.reduce in place (fast)"""
+        if self.backend == "nccl":
+            if self.timing:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record(self.stream)
+            if self.order == "fast":
+                dist.reduce(ds, dst=self.root, op=dist.ReduceOp.SUM, group=self.group)          # RCCL over xGMI
+            else:
+                into = list(self.gath.split(ds.numel())) if self.rank == self.root else None
+                dist.gather(ds, into, dst=self.root, group=self.group)                          # RCCL send / recv
+            if self.timing:
+                ev[1].record(self.stream)
+                self._pairs.append(ev)
+            return
+        # rehearsal (gloo): through host memory
+        if self.stream is not None:
+            self.stream.synchronize()
+        t = ds.cpu()
+        if self.order == "fast":
+            dist.reduce(t, dst=self.root, op=dist.ReduceOp.SUM, group=self.group)
+            ds.copy_(t)
+        else:
+            into = [torch.empty_like(t) for _ in range(self.world)] if self.rank == self.root else None
+            dist.gather(t, into, dst=self.root, group=self.group)
+            if into is not None:
+                for r, piece in enumerate(into):
+                    self.gath[r * t.numel():(r + 1) * t.numel()].copy_(piece)
+
     def queue(self, set_index, nseg):
         h, ds = self.h, self.buffer(set_index)
         h.select_set(set_index)
+        nfl = nseg * h.ave_per_seg
+        final = ds
         with self._on_stream():
             if self.parts & 1:
                 if self.source == "codes":
                     h.coadd_local_codes(nseg, ds.data_ptr())
-                else:
+                elif self.order == "fast":
                     h.coadd_local(nseg, ds.data_ptr())
+                elif self.node_per_rank:
+                    h.coadd_local_tree(nseg, self.local_order, ds.data_ptr())
+                else:
+                    for j in range(h.nant):
+                        h.coadd_local_tree(nseg, [j], ds.data_ptr() + 4 * self.n * j)
             if self.parts & 2 and self.world > 1:
-                if self.backend == "nccl":
-                    if self.timing:
-                        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                        ev[0].record(self.stream)
-                    dist.reduce(ds, dst=self.root, op=dist.ReduceOp.SUM, group=self.group)      # RCCL over xGMI
-                    if self.timing:
-                        ev[1].record(self.stream)
-                        self._pairs.append(ev)
-                else:                              # rehearsal (gloo): through host memory
-                    if self.stream is not None:
-                        self.stream.synchronize()
-                    t = ds.cpu()
-                    dist.reduce(t, dst=self.root, op=dist.ReduceOp.SUM, group=self.group)
-                    ds.copy_(t)
+                self._collective(ds)
             if self.rank == self.root and self.parts & 4:
-                h.coadd_finish(nseg, ds.data_ptr(), self.nant_total, blocking=False)
+                if self.order == "tree" and self.world > 1:
+                    h.coadd_tree(self.leaves, self.total.data_ptr(), nfl)
+                    final = self.total
+                h.coadd_finish(nseg, final.data_ptr(), self.nant_total, blocking=False)
             if self.use_target:
                 h.coadd_release()
         self.queued += 1
@@ -154,8 +235,15 @@ class IncoherentCoadd(object):
         return getattr(self.h, "cur_set", 0)
 
     def close(self):
+        """Detach from the handle: nothing of this object (its stream, its buffers) is referenced by the library
+        afterwards, whatever is done with the handle later."""
+        self.h.sync()
+        if self.stream is not None:
+            self.stream.synchronize()
+        self.h.set_coadd_stream(0)
         if self.use_target:
-            self.h.sync()
             for st in range(self.h.nsets):
                 self.h.select_set(st)
                 self.h.set_coadd_target(0)
+            self.h.select_set(0)
+            self.use_target = False

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Coadder host: BASELINE configs[3] -- N antenna streams sharded over the GPUs of a node, every antenna through the
-baseband -> filterbank path, the incoherent sum as ONE fp32 RCCL reduce per second to the root GPU, a single coadded
+baseband -> filterbank path, the incoherent sum as ONE fp32 RCCL gather (or reduce) per second to the root GPU, a single coadded
 SIGPROC file (station 99) and the coadded ring.
 
 What it replaces in the reference: one `process_baseband ... -C <co_key>` per antenna host writing its excised 8-bit
@@ -9,8 +9,12 @@ the station-99 name, :272-285, :987), and the external MPI coadder `agdadacoadd`
 starts with one rank per antenna ring under mpirun and that leaves the sum in a ring on the root host.  Here one
 process per GPU does both jobs: rank r takes antennas a with a mod world == r (coadd.antennas_of_rank), batches them
 in one PbHandle, and per second
-    pb_submit_vdif x A -> pb_process -> pb_coadd_local -> dist.reduce(fp32, root) -> root: pb_coadd_finish
-(coadd.IncoherentCoadd, on a stream of its own, one second behind the batch).  The root writes
+    pb_submit_vdif x A -> pb_process -> pb_coadd_local_tree -> dist.gather(fp32, root) -> root: pb_coadd_tree,
+    pb_coadd_finish
+(coadd.IncoherentCoadd, on a stream of its own, one second behind the batch).  The fp32 additions follow a DEFINED
+order (antennas split by index parity, recursively: coadd.py), so the coadded file is the same
+bytes whatever the number of ranks; `--coadd-order fast` takes one RCCL reduce instead, whose association is the
+collective's.  The root writes
 `<datadir>/<stamp>_muos_ea99_kur.fil` (`..._ea99.fil` in RFI mode 0) with the SIGPROC header of
 write_sigproc_header (telescope_id 99) and, with -K / --out-sink, the coadded ring; every rank also writes its
 antennas' own .fil / _kur.fil exactly as process_baseband does (-w 0 turns those off).
@@ -68,6 +72,9 @@ def build_parser():
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal: reduce through host memory)")
     p.add_argument("--coadd-input", choices=["planes", "codes"], default="planes",
                    help="what is summed: the fp32 planes before quantisation (default) or the antennas' quantised codes")
+    p.add_argument("--coadd-order", choices=["tree", "fast"], default="tree",
+                   help="tree (default): the defined order of the fp32 additions, the same bytes on any number of ranks; "
+                        "fast: one reduce(SUM), order left to the collective")
     p.add_argument("--share-gpus", action="store_true", help="rehearsal only: ranks may wrap onto the cards")
     return p
 
@@ -148,7 +155,10 @@ def run(args, rank=0, world=1, local=0, rings=None, handle=None, dist=None, devi
                              fft_backend=lp.FFT_LDS if args.fft_backend == "lds" else lp.FFT_HIPFFT, rows_per_seg=R,
                              max_seg=SEG_PER_SEC, keep_ave=True, nsets=args.nsets)
     if coadd is None:
-        coadd = cmod.IncoherentCoadd(handle, nant, device, root=0, backend=args.dist_backend, source=args.coadd_input)
+        coadd = cmod.IncoherentCoadd(handle, nant, device, root=0, backend=args.dist_backend, source=args.coadd_input,
+                                     order=args.coadd_order)
+    log("INFO", "Incoherent sum: %s of %d antennas over %d rank(s), order \"%s\"."
+        % (args.coadd_input, nant, world, getattr(coadd, "order", args.coadd_order)))
     ctl = Control(dist, args.dist_backend)
     trim, nsets = handle.trim, handle.nsets
     root = rank == 0
@@ -160,171 +170,201 @@ def run(args, rank=0, world=1, local=0, rings=None, handle=None, dist=None, devi
     written = []
     tsamp = 12500.0 / 128e6 * 8
 
-    while True:
-        # ---- observation set-up: headers, first frames, the common start second
-        log("INFO", "Waiting for DADA headers.")
-        hdrs, firsts = {}, {}
-        ok = 1
-        for a in mine:
-            raw_hdr = rings[a].next_header()
-            if raw_hdr is None:
-                ok = 0
-                break
-            hdrs[a] = vdif.ascii_header_parse(raw_hdr)
-            f = rings[a].read(vdif.VD_FRM)
-            if len(f) != vdif.VD_FRM:
-                log("ERR", "Problem reading first bloody frame!  Bailing.")
-                ok = 0
-                break
-            firsts[a] = f
-        if not ctl.min(ok)[0]:
-            log("INFO", "An input ring closed.  Exiting.")
-            break
-        log("INFO", "Beginning new observation.")
-        vhs = {a: vdif.unpack_header(firsts[a]) for a in mine}
-        e_lo, = ctl.min(min(v["epoch"] for v in vhs.values()))
-        e_hi, s0 = ctl.max(max(v["epoch"] for v in vhs.values()), max(v["second"] for v in vhs.values()))
-        if e_lo != e_hi:
-            log("ERR", "Antenna streams carry different VDIF epochs (%d, %d)!" % (e_lo, e_hi))
-            exit_status = 1
-            break
-        if blocks is None:
-            blocks = [[pbmod._pinned_bytes(sec_bytes) for _ in range(nsets + 1)] for _ in mine]
-        readers = [pbmod.SecondReader(rings[a], firsts[a], sec_bytes, log) for a in mine]
-        for i in range(A):
-            handle.reset_history(i)
-        # antennas that started early skip whole seconds up to the common start
-        ok = 1
-        for i, rd in enumerate(readers):
-            while ok and rd.current_sec < s0:
-                have, nh = rd.fill(blocks[i][0])
-                if have is None:
-                    ok = 0
-                else:
-                    rd.advance()
-            if rd.current_sec != s0:
-                ok = 0
-        if not ctl.min(ok)[0]:
-            log("ERR", "Antenna streams do not overlap in time; nothing to coadd.")
-            exit_status = 1
-            break
-        vh0 = dict(vhs[mine[0]], second=s0, frame=0, thread=0)
-        t_unix = vdif.vdif_to_unixepoch(vh0)
-        dmjd = vdif.frame_dmjd(vh0, frames_per_sec)
-        # ---- files: every antenna's own (as process_baseband), the coadded one on the root
-        fps = []
-        for a in mine:
-            station = int(hdrs[a].get("STATIONID", 0))
-            fb, fb_kur, cofb, cofb_kur = sigproc.fb_names(t_unix, station, args.datadir)
-            if args.write_fb == 0:
-                fb = fb_kur = os.devnull
-            sp = sigproc.sigproc_header(station, float(hdrs[a].get("RA", 0)), float(hdrs[a].get("DEC", 0)),
-                                        hdrs[a].get("NAME", ""), dmjd, args.npol, args.nbit)
-            main_fp = open(fb if args.rfi_mode in (0, 2) else fb_kur, "wb")
-            kur_fp = open(fb_kur, "wb") if args.rfi_mode == 2 else None
-            main_fp.write(sp)
-            if kur_fp:
-                kur_fp.write(sp)
-            fps.append((main_fp, kur_fp))
-            written.append((fb, fb_kur))
-        co_fp, co_name = None, None
-        if root:
-            h0 = hdrs[mine[0]]
-            co_name = cofb_kur if args.rfi_mode else cofb
-            co_fp = open(co_name, "wb")
-            co_fp.write(sigproc.sigproc_header(COADD_STATION, float(h0.get("RA", 0)), float(h0.get("DEC", 0)),
-                                               h0.get("NAME", ""), dmjd, args.npol, args.nbit))
-            log("INFO", "Writing the coadded filterbank of %d antennas to %s." % (nant, co_name))
-            if out_ring is not None:
-                oh = dict(h0, STATIONID=str(COADD_STATION))
-                out_ring.write_header(vdif.ascii_header_format(sigproc.psrdada_out_header(
-                    oh, vh0, args.npol, args.nbit, co_name, t_unix, vdif.frame_mjd(vh0), vdif.frame_mjd_sec(vh0))))
-        st = dict(done=0, co_written=0, fb_bytes=0)
-        t_obs = time.time()
-
-        def write_coadded(age):
-            v = coadd.coadded(SEG_PER_SEC, age=age)
-            if v is None:
-                return
-            b = np.array(v, copy=True)
-            co_fp.write(b.tobytes())
-            if out_ring is not None:
-                out_ring.write(b)
-            st["co_written"] += 1
-
-        def collect(k):
-            """second k: every local antenna's bytes -> its files; its incoherent-sum leg is queued now (the batch is
-            known to be complete), and the root writes the coadded bytes of the second before"""
-            handle.select_set(k % nsets)
-            for i in range(A):
-                out = handle.fetch(i, 0, SEG_PER_SEC, raw=args.rfi_mode != 1, kur=args.rfi_mode != 0)
-                main_fp, kur_fp = fps[i]
-                main_fp.write((out["raw"] if args.rfi_mode != 1 else out["kur"]).tobytes())
-                if kur_fp:
-                    kur_fp.write(out["kur"].tobytes())
-            st["fb_bytes"] += SEG_PER_SEC * trim
-            coadd.queue(k % nsets, SEG_PER_SEC)
-            if root and k >= 1:
-                write_coadded(1)
-            st["done"] += 1
-
-        queued = 0
+    open_files = []
+    try:
         while True:
-            ok, skip = 1, 0
-            haves = []
-            for i, rd in enumerate(readers):
-                have, nh = rd.fill(blocks[i][queued % (nsets + 1)])
-                if have is None:
+            # ---- observation set-up: headers, first frames, the common start second
+            log("INFO", "Waiting for DADA headers.")
+            hdrs, firsts = {}, {}
+            ok = 1
+            for a in mine:
+                raw_hdr = rings[a].next_header()
+                if raw_hdr is None:
                     ok = 0
                     break
-                if nh["second"] - rd.current_sec > 1:
-                    log("ERR", "Major data skip!  (%d vs. %d; thread = %d) Aborting this observation."
-                        % (nh["second"], rd.current_sec, nh["thread"]))
-                    skip = 1
-                if rd.current_sec != s0 + queued:
-                    skip = 1
-                haves.append(have)
-            ok, nskip = ctl.min(ok, -skip)
-            if nskip:
+                hdrs[a] = vdif.ascii_header_parse(raw_hdr)
+                f = rings[a].read(vdif.VD_FRM)
+                if len(f) != vdif.VD_FRM:
+                    log("ERR", "Problem reading first bloody frame!  Bailing.")
+                    ok = 0
+                    break
+                firsts[a] = f
+            if not ctl.min(ok)[0]:
+                log("INFO", "An input ring closed.  Exiting.")
+                break
+            log("INFO", "Beginning new observation.")
+            vhs = {a: vdif.unpack_header(firsts[a]) for a in mine}
+            e_lo, = ctl.min(min(v["epoch"] for v in vhs.values()))
+            e_hi, s0 = ctl.max(max(v["epoch"] for v in vhs.values()), max(v["second"] for v in vhs.values()))
+            if e_lo != e_hi:
+                log("ERR", "Antenna streams carry different VDIF epochs (%d, %d)!" % (e_lo, e_hi))
                 exit_status = 1
                 break
-            if not ok:
-                break                                   # a stream has ended: its last second is dropped, the sum ends
-            handle.select_set(queued % nsets)
+            if blocks is None:
+                blocks = [[pbmod._pinned_bytes(sec_bytes) for _ in range(nsets + 1)] for _ in mine]
+            readers = [pbmod.SecondReader(rings[a], firsts[a], sec_bytes, log) for a in mine]
+            for i in range(A):
+                handle.reset_history(i)
+            # antennas that started early skip whole seconds up to the common start
+            ok = 1
             for i, rd in enumerate(readers):
-                blk = blocks[i][queued % (nsets + 1)]
-                rd.seal(blk, haves[i])
-                handle.submit_vdif(i, 0, blk, second=rd.current_sec, frame0=0)
-            handle.process(SEG_PER_SEC, 0)
-            for rd in readers:
-                rd.advance()
-            queued += 1
-            if queued - st["done"] >= nsets:
+                while ok and rd.current_sec < s0:
+                    have, nh = rd.fill(blocks[i][0])
+                    if have is None:
+                        ok = 0
+                    else:
+                        rd.advance()
+                if rd.current_sec != s0:
+                    ok = 0
+            if not ctl.min(ok)[0]:
+                log("ERR", "Antenna streams do not overlap in time; nothing to coadd.")
+                exit_status = 1
+                break
+            vh0 = dict(vhs[mine[0]], second=s0, frame=0, thread=0)
+            t_unix = vdif.vdif_to_unixepoch(vh0)
+            dmjd = vdif.frame_dmjd(vh0, frames_per_sec)
+            # ---- files: every antenna's own (as process_baseband), the coadded one on the root
+            fps = []
+            # every antenna's own files are named by (second, STATIONID) alone: two streams with one id would open
+            # the same files and interleave their writes
+            st_vec = [-1] * nant
+            for a in mine:
+                st_vec[a] = int(hdrs[a].get("STATIONID", 0))
+            st_all = ctl.max(*st_vec)
+            if args.write_fb != 0 and len(set(st_all)) != nant:
+                dup = sorted(set(x for x in st_all if st_all.count(x) > 1))
+                log("ERR", "Antenna streams share STATIONID %s: their filterbank files would collide.  Give the streams "
+                           "distinct ids or run with -w 0 (coadded file only)." % dup)
+                exit_status = 1
+                break
+            allow = pbmod.load_write_allow(log=log) if args.write_fb == 1 else None
+            for a in mine:
+                station = int(hdrs[a].get("STATIONID", 0))
+                fb, fb_kur, cofb, cofb_kur = sigproc.fb_names(t_unix, station, args.datadir)
+                to_null = args.write_fb == 0
+                if args.write_fb == 1:           # the reference's source selection, per antenna (src/process_baseband.cu:880-923)
+                    if pbmod.source_allowed(hdrs[a], allow):
+                        log("INFO", "Source %s matches target list, recording filterbank data." % hdrs[a].get("NAME", ""))
+                    else:
+                        to_null = True
+                        log("INFO", "Source %s not on target list, disabling filterbank data." % hdrs[a].get("NAME", ""))
+                if to_null:
+                    fb = fb_kur = os.devnull
+                sp = sigproc.sigproc_header(station, float(hdrs[a].get("RA", 0)), float(hdrs[a].get("DEC", 0)),
+                                            hdrs[a].get("NAME", ""), dmjd, args.npol, args.nbit)
+                main_fp = open(fb if args.rfi_mode in (0, 2) else fb_kur, "wb")
+                kur_fp = open(fb_kur, "wb") if args.rfi_mode == 2 else None
+                main_fp.write(sp)
+                if kur_fp:
+                    kur_fp.write(sp)
+                fps.append((main_fp, kur_fp))
+                open_files.extend(f for f in (main_fp, kur_fp) if f)
+                written.append((fb, fb_kur))
+            co_fp, co_name = None, None
+            if root:
+                h0 = hdrs[mine[0]]
+                co_name = cofb_kur if args.rfi_mode else cofb
+                co_fp = open(co_name, "wb")
+                open_files.append(co_fp)
+                co_fp.write(sigproc.sigproc_header(COADD_STATION, float(h0.get("RA", 0)), float(h0.get("DEC", 0)),
+                                                   h0.get("NAME", ""), dmjd, args.npol, args.nbit))
+                log("INFO", "Writing the coadded filterbank of %d antennas to %s." % (nant, co_name))
+                if out_ring is not None:
+                    oh = dict(h0, STATIONID=str(COADD_STATION))
+                    out_ring.write_header(vdif.ascii_header_format(sigproc.psrdada_out_header(
+                        oh, vh0, args.npol, args.nbit, co_name, t_unix, vdif.frame_mjd(vh0), vdif.frame_mjd_sec(vh0))))
+            st = dict(done=0, co_written=0, fb_bytes=0)
+            t_obs = time.time()
+
+            def write_coadded(age):
+                v = coadd.coadded(SEG_PER_SEC, age=age)
+                if v is None:
+                    return
+                b = np.array(v, copy=True)
+                co_fp.write(b.tobytes())
+                if out_ring is not None:
+                    out_ring.write(b)
+                st["co_written"] += 1
+
+            def collect(k):
+                """second k: every local antenna's bytes -> its files; its incoherent-sum leg is queued now (the batch is
+                known to be complete), and the root writes the coadded bytes of the second before"""
+                handle.select_set(k % nsets)
+                for i in range(A):
+                    out = handle.fetch(i, 0, SEG_PER_SEC, raw=args.rfi_mode != 1, kur=args.rfi_mode != 0)
+                    main_fp, kur_fp = fps[i]
+                    main_fp.write((out["raw"] if args.rfi_mode != 1 else out["kur"]).tobytes())
+                    if kur_fp:
+                        kur_fp.write(out["kur"].tobytes())
+                st["fb_bytes"] += SEG_PER_SEC * trim
+                coadd.queue(k % nsets, SEG_PER_SEC)
+                if root and k >= 1:
+                    write_coadded(1)
+                st["done"] += 1
+
+            queued = 0
+            while True:
+                ok, skip = 1, 0
+                haves = []
+                for i, rd in enumerate(readers):
+                    have, nh = rd.fill(blocks[i][queued % (nsets + 1)])
+                    if have is None:
+                        ok = 0
+                        break
+                    if nh["second"] - rd.current_sec > 1:
+                        log("ERR", "Major data skip!  (%d vs. %d; thread = %d) Aborting this observation."
+                            % (nh["second"], rd.current_sec, nh["thread"]))
+                        skip = 1
+                    if rd.current_sec != s0 + queued:
+                        skip = 1
+                    haves.append(have)
+                ok, nskip = ctl.min(ok, -skip)
+                if nskip:
+                    exit_status = 1
+                    break
+                if not ok:
+                    break                                   # a stream has ended: its last second is dropped, the sum ends
+                handle.select_set(queued % nsets)
+                for i, rd in enumerate(readers):
+                    blk = blocks[i][queued % (nsets + 1)]
+                    rd.seal(blk, haves[i])
+                    handle.submit_vdif(i, 0, blk, second=rd.current_sec, frame0=0)
+                handle.process(SEG_PER_SEC, 0)
+                for rd in readers:
+                    rd.advance()
+                queued += 1
+                if queued - st["done"] >= nsets:
+                    collect(st["done"])
+            while st["done"] < queued:
                 collect(st["done"])
-        while st["done"] < queued:
-            collect(st["done"])
-        if root and queued:
-            write_coadded(0)
-        for main_fp, kur_fp in fps:
-            main_fp.close()
-            if kur_fp:
-                kur_fp.close()
-        if root:
-            co_fp.close()
-            if out_ring is not None:
-                out_ring.end_of_data()
-            nsamp = st["co_written"] * SEG_PER_SEC * trim * (8 // args.nbit) // 4096
-            log("INFO", "Wrote %.2f MB (%.2f s) to %s" % (st["co_written"] * SEG_PER_SEC * trim * 1e-6, nsamp * tsamp, co_name))
-        for a in mine:
-            if hasattr(rings[a], "finish_observation"):
-                rings[a].finish_observation()
-        log("INFO", "Proc Time...%.3f" % (time.time() - t_obs))
-        if exit_status:
-            break
-    if hasattr(coadd, "close"):
-        coadd.close()
-    if own_handle:
-        handle.close()
+            if root and queued:
+                write_coadded(0)
+            for main_fp, kur_fp in fps:
+                main_fp.close()
+                if kur_fp:
+                    kur_fp.close()
+            if root:
+                co_fp.close()
+                if out_ring is not None:
+                    out_ring.end_of_data()
+                nsamp = st["co_written"] * SEG_PER_SEC * trim * (8 // args.nbit) // 4096
+                log("INFO", "Wrote %.2f MB (%.2f s) to %s" % (st["co_written"] * SEG_PER_SEC * trim * 1e-6, nsamp * tsamp, co_name))
+            for a in mine:
+                if hasattr(rings[a], "finish_observation"):
+                    rings[a].finish_observation()
+            log("INFO", "Proc Time...%.3f" % (time.time() - t_obs))
+            if exit_status:
+                break
+    finally:
+        # (also on an exception: nothing of the leg -- its stream, its buffers -- stays referenced by the handle,
+        #  and no file is left open)
+        for fp in open_files:
+            if not fp.closed:
+                fp.close()
+        if hasattr(coadd, "close"):
+            coadd.close()
+        if own_handle:
+            handle.close()
     run.last_files = written
     return exit_status
 

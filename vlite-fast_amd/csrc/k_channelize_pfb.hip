@@ -56,22 +56,7 @@ struct PfbArgs {
     const float2 *tw2, *tw3, *postc;
     FrbParams frb;
     int R, rfi_mode, inject_now;
-    // k_channelize_pfb_kur only (the channeliser that flags its own rows)
-    uint8_t *flags_out;      // = flags
-    float *wrow_out;         // = wrow
-    uint32_t *info;          // = rowmask: per row (epoch << 27) | (code 0 seen << 25) | flag mask, published by the row's workgroup
-    const DagConsts *dag;
-    const float *tapE;       // [101] window energy per (tap, block), and their sum
-    uint32_t *gave_up;       // mapped host word: a look-back wait ran out (must stay 0)
-    unsigned epoch;          // 1..31, this launch's
-    int dbg;                 // PB_PFB_DBG (timing experiments, results invalid): 1 no staging of the own row and no moments,
-                             // the row's flags taken from the bytes an earlier launch left for the same input; 2 the
-                             // predecessors' words by ordinary loads, whatever their epoch (no look-back wait)
-    int strip_shift;         // rows -> workgroups: strips of 1 << strip_shift rows per XCD (-1: row = blockIdx.x)
 };
-#ifndef PFB_SPIN_LIMIT
-#define PFB_SPIN_LIMIT (1 << 16)   // polls of a predecessor's word before a workgroup gives up (~0.1 s: a lost producer)
-#endif
 
 __device__ __forceinline__ unsigned row_mask(const PfbArgs &a, int ant, int rr)
 {
@@ -88,13 +73,9 @@ __device__ __forceinline__ unsigned row_mask(const PfbArgs &a, int ant, int rr)
 // contributing rows has a flagged block), ROLE 1 = excised spectrum.  The masks and the weight are scalar loads
 // requested at the top of the kernel; ROLE 0 first needs them after the FFT, so their latency and that of the
 // rows' bytes run side by side.
-// FUSED (k_channelize_pfb_kur): the input buffer has not been patched for code 0, and masks / weight come from `smw`
-// (words 0..3: zeroing masks of rows g-3..g, bit 25 = that row holds a code 0; word 4: the weight), which wave 0
-// fills while the other waves are already staging: they are read behind the staging barrier.
-template <int role, bool FUSED = false, class Hook = NoHook>
+template <int role>
 __device__ __forceinline__ void pfb_pass(const PfbArgs &a, uint8_t *lds, int tid, int grow, int seg, int row, int pol,
-                                         int ant, const unsigned (&mask_in)[4], unsigned differ, float w, size_t prow,
-                                         const unsigned *smw = nullptr, Hook hook = Hook())
+                                         int ant, const unsigned (&mask)[4], unsigned differ, float w, size_t prow)
 {
     f2 *buf = (f2 *)lds;
     // window coefficients of samples (2n, 2n+1), n = tid + 250 r, tap j: through a buffer descriptor
@@ -174,33 +155,10 @@ __device__ __forceinline__ void pfb_pass(const PfbArgs &a, uint8_t *lds, int tid
 #endif
         }
     }
-    hook();      // (FUSED: what wave 0 still owes smw, done while the rows are on their way)
 #if PFB_STAGE_DMA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     __syncthreads();
-    unsigned mask[4] = {mask_in[0], mask_in[1], mask_in[2], mask_in[3]};
-    if (FUSED) {
-        unsigned fix = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned m = __builtin_amdgcn_readfirstlane(smw[j]);
-            mask[j] = m & 0x1ffffffu;
-            fix |= ((m >> 25) & 1u) << j;
-        }
-        differ = mask[0] | mask[1] | mask[2] | mask[3];
-        w = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(smw[4]));
-        if (fix) {
-            // rare (dropped frames): a contributing row holds code 0 ("no sample" = 0.0 = code 128); patch it in LDS
-#pragma unroll 1
-            for (int j = 0; j < 4; ++j) {
-                if (!((fix >> j) & 1u)) continue;
-                uint4 *dst = (uint4 *)(lds + j * PFB_ROW_LDS);
-                for (int i = tid; i < PFB_ROW_LDS / 16; i += 256) dst[i] = fix_zero_codes(dst[i]);
-            }
-            __syncthreads();
-        }
-    }
 
     f2 v[25];
     if (tid < 250) {
@@ -339,215 +297,6 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
 }
 
 
-// taps = 4, the channeliser that flags its own rows (as k_channelize_kur does for the rectangular window): one
-// workgroup per row, both pols.  It computes the kurtosis flags of ITS row from the bytes it stages, publishes them
-// as one word, and takes the words of rows g-3 .. g-1 from the workgroups that own them (history slots for the first
-// three rows of a batch): no kurtosis pass over the input in front of the channeliser, no weights kernel.
-//
-// Look-back without deadlock: a workgroup publishes its word BEFORE it waits for anybody else's, so a wait ends as
-// soon as the awaited workgroup has been dispatched and has done its statistic.  Rows go to workgroups in strips of
-// K = 1 << strip_shift consecutive rows per XCD (an input row is read by four consecutive output rows: three of the
-// four reads hit the XCD's own L2, as with k_channelize_pfb's eighths), interleaved so that a predecessor row's
-// workgroup is either earlier in dispatch order or at most 8 K - 1 workgroups later (the first three rows of a strip
-// look back into the neighbouring XCD's strip): with K <= 32 well inside the ~768 workgroups in flight.  The wait is
-// bounded anyway (PFB_SPIN_LIMIT): a workgroup that gives up says so in `gave_up` and the host fails the batch.
-__global__ __launch_bounds__(256, 3) void k_channelize_pfb_kur(PfbArgs a)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * PFB_ROW_LDS];   // 50 112 B, reused as the FFT buffer
-    __shared__ float smom[100];       // sum x^2, sum x^4 of the row's 2 x 25 blocks
-    __shared__ unsigned smw[10];      // masks and weight of the window's four rows (layout at hook_resolve)
-    __shared__ unsigned szw[4];       // per wave: a staged chunk of the own row held a code 0
-    int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int row = blockIdx.x;
-    if (a.strip_shift >= 0) {
-        const int i = (int)(blockIdx.x >> 3), x = (int)(blockIdx.x & 7), ks = a.strip_shift;
-        row = ((i >> ks) << (ks + 3)) + (x << ks) + (i & ((1 << ks) - 1));
-    }
-    const int seg = blockIdx.y, ant = blockIdx.z;
-    const int grow = seg * a.R + row;
-
-    // ---- the own row, both pols, through registers into slots 0 and 1, patched for code 0
-    const size_t rb0 = (size_t)ant * a.in_ant_stride + (size_t)seg * 2 * a.seg_samples + (size_t)row * PB_NFFT;
-    const size_t rb1 = rb0 + a.seg_samples;
-    const unsigned off0 = (unsigned)(rb0 & 15), off1 = (unsigned)(rb1 & 15);
-    if (!(a.dbg & 1)) {
-        const uint4 *s0 = (const uint4 *)(a.in + (rb0 - off0)), *s1 = (const uint4 *)(a.in + (rb1 - off1));
-        const bool h0 = tid + 768 < (int)((off0 + PB_NFFT + 15) >> 4), h1 = tid + 768 < (int)((off1 + PB_NFFT + 15) >> 4);
-        const uint4 a0 = s0[tid], a1 = s0[tid + 256], a2 = s0[tid + 512];
-        const uint4 b0 = s1[tid], b1 = s1[tid + 256], b2 = s1[tid + 512];
-        uint4 a3 = make_uint4(0u, 0u, 0u, 0u), b3 = a3;
-        if (h0) a3 = s0[tid + 768];
-        if (h1) b3 = s1[tid + 768];
-        uint4 *d0 = (uint4 *)lds, *d1 = (uint4 *)(lds + PFB_ROW_LDS);
-        unsigned zz = 0;
-        auto put = [&](uint4 *dst, int i, uint4 q) __attribute__((always_inline)) {
-            const uint4 f = fix_zero_codes(q);
-            dst[i] = f;
-            zz |= (f.x ^ q.x) | (f.y ^ q.y) | (f.z ^ q.z) | (f.w ^ q.w);
-        };
-        put(d0, tid, a0); put(d0, tid + 256, a1); put(d0, tid + 512, a2);
-        put(d1, tid, b0); put(d1, tid + 256, b1); put(d1, tid + 512, b2);
-        if (h0) put(d0, tid + 768, a3);
-        if (h1) put(d1, tid + 768, b3);
-        // (boundary chunks carry a few of the neighbouring rows' bytes: a code 0 there sets the bit needlessly, harmless)
-        const bool anyz = __ballot(zz != 0) != 0;
-        if (lane == 0) szw[wave] = anyz ? 1u : 0u;
-    }
-    const DagConsts dc = *a.dag;
-    __syncthreads();
-    if (!(a.dbg & 1)) row_block_moments(lds + off0, lds + PFB_ROW_LDS + off1, wave, lane, smom, smom + 50);
-    else if (tid < 100) smom[tid] = tid < 50 ? 8.7f : 0.45f;
-    __syncthreads();
-
-    // ---- wave 0: flags, the row's word; the predecessors' words are REQUESTED here and looked at in the hook of the
-    //      first transform's staging (behind the flags' arithmetic and the staging requests: by then they have landed,
-    //      and normally they hold this launch's epoch -- the predecessors started earlier).  The other waves go straight
-    //      on to stage the first transform's rows; smw is read behind that transform's staging barrier.
-    unsigned lb = 0;                  // lane j < 3 of wave 0: the word of row g - 3 + j as first seen
-    uint32_t own = 0;                 // wave 0: this row's mask | code-0 bit << 25
-    const size_t wi = (size_t)ant * a.wrow_ant_stride;
-    if (wave == 0) {
-        if (lane < 3 && grow - 3 + lane >= 0)
-            lb = (a.dbg & 2) ? a.info[wi + (grow - 3 + lane)]      // (timing: an ordinary cached load of whatever is there)
-                             : __hip_atomic_load(a.info + wi + (grow - 3 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        bool f = false;
-        if (lane < 50) {
-            const float p = smom[lane] / PB_NKURTO;
-            const float k = smom[50 + lane] / PB_NKURTO / (p * p);
-            f = dag_flag(k, dc);
-        }
-        if (a.dbg & 1) f = lane < 25 && a.flags_out[(size_t)ant * a.flags_ant_stride + (size_t)grow * PB_BLK_PER_FFT + lane] != 0;
-        // bit b = block b flagged in pol 0 or pol 1 (compute_dagostino's max over pols, src/pb_kernels.cu:109-134)
-        const unsigned long long bal = __ballot(f);
-        const uint32_t m = (uint32_t)((bal | (bal >> 25)) & 0x1ffffffull);
-        const uint32_t zbit = (szw[0] | szw[1] | szw[2] | szw[3]) & 1u;
-        own = m | (zbit << 25);
-        if (lane == 0)
-            __hip_atomic_store(a.info + wi + grow, (a.epoch << 27) | own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (lane < 25) a.flags_out[(size_t)ant * a.flags_ant_stride + (size_t)grow * PB_BLK_PER_FFT + lane] = (m >> lane) & 1u;
-    }
-    // the weight: unflagged share of the window's energy, (tap, block) ascending (k_pfb_weights' sum); 0.7 us of
-    // dependent additions, needed by the EXCISED transform's last step only (an unflagged window weighs exactly 1)
-    auto weight_sum = [&](const unsigned (&wm)[4]) __attribute__((always_inline)) {
-        // the 101 energies across the lanes (two loads), then a rolled loop: readlane + add per term -- the order of the
-        // additions is the definition, so the sum is serial whatever is done; unrolled it was 400 instructions, twice
-        const float elo = a.tapE[lane], ehi = lane < 37 ? a.tapE[64 + lane] : 0.f;
-        const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ehi), 36));
-        float sm = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned mj = wm[j];
-#pragma unroll 1
-            for (int b = 0; b < PB_BLK_PER_FFT; ++b) {
-                const int i = j * PB_BLK_PER_FFT + b;
-                const int e = i < 64 ? __builtin_amdgcn_readlane(__builtin_bit_cast(int, elo), i)
-                                     : __builtin_amdgcn_readlane(__builtin_bit_cast(int, ehi), i - 64);
-                if (!((mj >> b) & 1u)) sm = sm + __builtin_bit_cast(float, e);
-            }
-        }
-        return sm / tot;
-    };
-    // smw: [0..3] zeroing masks of rows g-3..g (bit 25: patch the row), [4] weight, [5..7] rows g-3..g-1 as the weight
-    // counts them, [8] 1 = the weight is still owed (hook_weight), [9] 1 = every contributing block flagged or missing
-    int pol = 0;
-    auto hook_resolve = [&]() __attribute__((always_inline)) {
-        if (wave != 0 || pol != 0) return;
-        unsigned wv = 0, ev = 0;
-        if (lane < 3) {
-            const int rr = grow - 3 + lane;
-            if (rr >= 0) {
-                unsigned v = lb;
-                int spins = 0;
-                while ((v >> 27) != a.epoch && !(a.dbg & 2)) {
-                    __builtin_amdgcn_s_sleep(4);
-                    v = __hip_atomic_load(a.info + wi + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (++spins > PFB_SPIN_LIMIT ||
-                        ((spins & 1023) == 0 && __hip_atomic_load(a.gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) {
-                        __hip_atomic_store(a.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        break;
-                    }
-                }
-                wv = v & 0x1ffffffu;
-                ev = v & 0x3ffffffu;
-            } else {
-                // the previous batch's last rows: flags kept by k_pfb_history (all set before the stream starts: such a
-                // row counts as missing in the weight; it is zeros, nothing to zero in it; pfb_pass patches history rows)
-                const uint8_t *hf = a.hflags + ((size_t)ant * 3 + (3 + rr)) * PB_BLK_PER_FFT;
-                for (int b = 0; b < PB_BLK_PER_FFT; ++b) wv |= (hf[b] ? 1u : 0u) << b;
-                ev = a.hvalid[ant * 3 + (3 + rr)] ? wv : 0u;
-            }
-        }
-        unsigned wm[4], em[4];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            wm[j] = __builtin_amdgcn_readlane(wv, j);
-            em[j] = __builtin_amdgcn_readlane(ev, j);
-        }
-        wm[3] = own & 0x1ffffffu;
-        em[3] = own;
-        const bool flagged = (wm[0] | wm[1] | wm[2] | wm[3]) != 0;
-        const bool differ = ((em[0] | em[1] | em[2] | em[3]) & 0x1ffffffu) != 0;
-        // owed: the raw transform of a row that differs does not look at the weight, the excised one's staging pays
-        const bool owed = flagged && differ && a.rfi_mode == 2;
-        float w = 1.0f;
-        if (flagged && !owed) w = weight_sum(wm);
-        if (lane == 0) {
-            smw[0] = em[0];
-            smw[1] = em[1];
-            smw[2] = em[2];
-            smw[3] = em[3];
-            smw[4] = __builtin_bit_cast(unsigned, w);
-            smw[5] = wm[0];
-            smw[6] = wm[1];
-            smw[7] = wm[2];
-            smw[8] = owed ? 1u : 0u;
-            smw[9] = (wm[0] & wm[1] & wm[2] & wm[3]) == 0x1ffffffu ? 1u : 0u;
-            if (!owed) a.wrow_out[wi + grow] = w;
-        }
-    };
-    auto hook_weight = [&]() __attribute__((always_inline)) {
-        if (wave != 0 || pol != 0 || !smw[8]) return;
-        const unsigned wm[4] = {smw[5], smw[6], smw[7], smw[3] & 0x1ffffffu};
-        const float w = weight_sum(wm);
-        if (lane == 0) {
-            smw[4] = __builtin_bit_cast(unsigned, w);
-            smw[8] = 0u;
-            a.wrow_out[wi + grow] = w;
-        }
-    };
-
-    const unsigned none[4] = {0, 0, 0, 0};
-#pragma unroll 1
-    for (pol = 0; pol < 2; ++pol) {
-        const size_t prow = (size_t)ant * a.p_ant_stride + (((size_t)seg * 2 + pol) * a.R + row) * PB_NCHANOUT;
-        if (pol) __syncthreads();   // the previous transform has finished reading the FFT buffer
-        if (a.rfi_mode != 1) {
-            pfb_pass<0, true>(a, lds, tid, grow, seg, row, pol, ant, none, 0u, 1.f, prow, smw, hook_resolve);
-        } else if (pol == 0) {
-            hook_resolve();         // (no raw transform in RFI mode 1: the masks are needed at once)
-            __syncthreads();
-        }
-        const unsigned differ = (__builtin_amdgcn_readfirstlane(smw[0]) | __builtin_amdgcn_readfirstlane(smw[1]) |
-                                 __builtin_amdgcn_readfirstlane(smw[2]) | __builtin_amdgcn_readfirstlane(smw[3])) & 0x1ffffffu;
-        if (a.rfi_mode == 2 && differ == 0) continue;
-        if (__builtin_amdgcn_readfirstlane(smw[9])) {      // weight 0: nothing of the window is left
-            for (int c = tid; c < PB_NCHANOUT; c += 256) a.Pkur[prow + c] = __builtin_inff();
-            if (pol == 0) {
-                __syncthreads();
-                hook_weight();
-            }
-            continue;
-        }
-        if (a.rfi_mode == 2) {
-            __syncthreads();   // the raw pass has finished reading the FFT buffer
-            asm volatile("" : "+v"(tid));   // no sharing of tid-derived addresses across the two passes
-        }
-        pfb_pass<1, true>(a, lds, tid, grow, seg, row, pol, ant, none, 0u, 1.f, prow, smw, hook_weight);
-    }
-}
-
 // row weights of the PFB mode (see the header comment); overwrites wrow[g]
 __global__ void k_pfb_weights(const uint32_t *__restrict__ rowmask, size_t wrow_ant_stride,
                               const uint8_t *__restrict__ hflags, const float *__restrict__ tapE,
@@ -643,38 +392,6 @@ hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now)
     a.R = h->R;
     a.rfi_mode = h->cfg.rfi_mode;
     a.inject_now = inject_now;
-    a.flags_out = h->d_flags;
-    a.wrow_out = h->d_wrow;
-    a.info = pb_rowmask(h);
-    a.dag = h->d_dag;
-    a.tapE = h->d_tapE;
-    a.gave_up = h->d_fg_error;
-    a.epoch = 0;
-    static const int pfb_dbg = getenv("PB_PFB_DBG") ? atoi(getenv("PB_PFB_DBG")) : 0;
-    a.dbg = h->processed > 0 ? pfb_dbg : 0;   // (the set must hold the flags of the same input)
-    a.strip_shift = -1;
-    if (pb_fused_kurtosis(h)) {
-        // one workgroup per row (both pols): it computes the row's flags itself and looks back for its predecessors'
-        uint32_t &ep = h->pfb_epoch[h->cur_set];
-        if (++ep > 31) {
-            // the words' five epoch bits come round: clear them (every launch writes the words of all its rows, so a
-            // word that still shows this epoch could only be 31 launches old)
-            hipError_t e = hipMemsetAsync(pb_rowmask(h), 0, (size_t)h->A * h->S * h->R * sizeof(uint32_t), h->stream);
-            if (e != hipSuccess) return e;
-            ep = 1;
-        }
-        a.epoch = ep;
-        if (h->R % 8 == 0) {
-            int ks = 0;
-            while (ks < 5 && h->R % (16 << ks) == 0) ++ks;      // the largest K = 1 << ks <= 32 with R a multiple of 8 K
-            a.strip_shift = ks;
-            static const int strip_env = getenv("PB_PFB_STRIP") ? atoi(getenv("PB_PFB_STRIP")) : -1;      // (timing experiments)
-            if (strip_env >= 0 && h->R % (8 << strip_env) == 0) a.strip_shift = strip_env;
-        }
-        dim3 gk((unsigned)h->R, (unsigned)nseg, (unsigned)h->A);
-        k_channelize_pfb_kur<<<gk, 256, 0, h->stream>>>(a);
-        return hipGetLastError();
-    }
     dim3 grid((unsigned)h->R, (unsigned)(nseg * 2), (unsigned)h->A);
     k_channelize_pfb<<<grid, 256, 0, h->stream>>>(a);
     return hipGetLastError();

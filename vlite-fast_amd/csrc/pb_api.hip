@@ -40,12 +40,27 @@ static int fail(pb_handle *h, int code, const std::string &msg)
 
 extern "C" const char *pb_version(void) { return "pb_hip 0.1 (gfx950)"; }
 
+// Launches left out on request -- RESULTS INVALID -- for the energy / upper-bound measurements of tools/energy_probe.py,
+// tools/taps1_unfused_bound.sh and tools/pfb_fused_ab.sh: bit 0 the channeliser, bit 1 detect, bit 2 the kurtosis pass.
+// Compiled only into the experiments build (`make exp` -> libpb_hip_exp.so, -DPB_EXPERIMENTS=1, selected with
+// PB_LIBPATH): the shipped library does not read the variable and cannot be talked into skipping a kernel.
+static inline int pb_skip_mask()
+{
+#if PB_EXPERIMENTS
+    static const int skip = getenv("PB_SKIP") ? atoi(getenv("PB_SKIP")) : 0;
+    return skip;
+#else
+    return 0;
+#endif
+}
+
 bool pb_fused_kurtosis(const pb_handle *h)
 {
-    // h->fuse (PB_FUSE_KURTOSIS when the handle was created): 0 never, 1 the rectangular window only (the default:
-    // for taps = 4 the fused kernel is bit-exact and SLOWER than kurtosis pass + channeliser, profiles/r04_notes.md
-    // section 10), 2 taps = 4 as well
-    if (h->fuse < (h->cfg.taps == 1 ? 1 : 2)) return false;
+    // h->fuse (PB_FUSE_KURTOSIS when the handle was created): 0 never, 1 (default) the rectangular window.  taps = 4
+    // keeps kurtosis pass + weights + channeliser: a channeliser that flags its own rows was built in round 4, was
+    // bit-exact and 17 % SLOWER (profiles/r04_notes.md section 10) and left the library in round 5
+    // (tools/experiments/k_channelize_pfb_kur.patch).
+    if (h->fuse < 1 || h->cfg.taps != 1) return false;
     return h->cfg.fft_backend == PB_FFT_LDS && h->cfg.rfi_mode != 0 && !h->cfg.debug_keep;
 }
 
@@ -316,7 +331,6 @@ static int create_impl(pb_handle *h)
     h->sets.resize(c.nsets);
     h->chunk_rows = (R % 32 == 0) ? 32 : 8;
     h->ready_epoch.assign(c.nsets, std::vector<uint32_t>(S, 0u));
-    h->pfb_epoch.assign(c.nsets, 0u);
     {
         // (mapped page-locked word: the device writes it only when a detect workgroup gives up waiting for a row)
         HIPCHK(h, hipHostMalloc((void **)&h->d_fg_error, sizeof(uint32_t), hipHostMallocMapped));
@@ -960,10 +974,10 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         if (e == hipSuccess && !fused) {
             {
                 StageTimer t(h, PB_ST_KURTOSIS);
-                static const int skip_kur = getenv("PB_SKIP") ? atoi(getenv("PB_SKIP")) & 4 : 0;   // (energy experiments)
-                // (only once the set holds the flags of the same input from an earlier call: the experiment re-processes
-                //  one second of data, and without flags there would be no excised transforms either)
-                if (!(skip_kur && h->processed > 0)) e = launch_kurtosis_flag(h, nseg, hipfft);
+                // (PB_SKIP & 4, PB_EXPERIMENTS builds only: only once the set holds the flags of the same input from an
+                //  earlier call -- the experiment re-processes one second of data, and without flags there would be no
+                //  excised transforms either)
+                if (!((pb_skip_mask() & 4) && h->processed > 0)) e = launch_kurtosis_flag(h, nseg, hipfft);
                 t.stop();
             }
             // taps = 4: the weights read the flags of the previous batch's last rows (history slot hist_rd, filled by
@@ -1012,16 +1026,8 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         }
     } else {
         StageTimer t(h, PB_ST_CHANNELIZE);
-        // (PB_SKIP=1 / 2, energy experiments only -- tools/energy_probe.py: leave out the channeliser / detect launch)
-        static const int skip = getenv("PB_SKIP") ? atoi(getenv("PB_SKIP")) : 0;
-        if (!(skip & 1))
+        if (!(pb_skip_mask() & 1))
             HIPCHK(h, h->cfg.taps == 4 ? launch_channelize_pfb(h, nseg, inject_now) : launch_channelize(h, nseg, inject_now));
-        if (h->cfg.taps == 4 && pb_fused_kurtosis(h)) {
-            // The fused channeliser has written the batch's flags: keep its last three rows and their flags for the next
-            // batch in the history slot this batch did not read.  Same stream as every channeliser: behind the previous
-            // one (which read that slot) and in front of the next (which will).
-            HIPCHK(h, launch_pfb_history(h, nseg));
-        }
         t.stop();
     }
     HIPCHK(h, hipEventRecord(h->ev_fftdone, h->stream));
@@ -1045,8 +1051,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         h->stream = h->s_det;
         if (e2 == hipSuccess) {
             StageTimer t(h, PB_ST_DETECT);
-            static const int skip_det = getenv("PB_SKIP") ? atoi(getenv("PB_SKIP")) & 2 : 0;
-            if (!skip_det) e2 = launch_detect(h, nseg, inject_now, fine);
+            if (!(pb_skip_mask() & 2)) e2 = launch_detect(h, nseg, inject_now, fine);
             t.stop();
         }
         if (e2 == hipSuccess) e2 = hipEventRecord(h->ev_chan, h->s_det);   // this set's kernels are done
@@ -1109,10 +1114,13 @@ extern "C" int pb_select_set(pb_handle *h, int set)
     return PB_OK;
 }
 
+// The fine-grained build's detect gives up (and says so in this mapped word) when a row it waits for never comes.
+// Fail-stop, like the reference's cudacheck (src/cuda_util.cu:4-12): the word is never cleared, every later call
+// that hands out results of this handle -- bytes, planes, device addresses, the coadd leg -- fails.
 static int check_fine_grained(pb_handle *h)
 {
     if (h->d_fg_error && *(volatile uint32_t *)h->d_fg_error)
-        return fail(h, PB_ESTATE, "a workgroup gave up waiting for another's rows (detect's row-ready counters, or the taps = 4 channeliser's look-back): results invalid");
+        return fail(h, PB_ESTATE, "a detect workgroup gave up waiting for the channeliser's rows (row-ready counters of the fine-grained build): results invalid");
     return PB_OK;
 }
 
@@ -1174,6 +1182,7 @@ extern "C" int pb_output_dev(pb_handle *h, int ant, int stream, void **codes, vo
     if (!h) return PB_EINVAL;
     if (check_ant(h, ant)) return PB_EINVAL;
     if (stream < 0 || stream > 1) return fail(h, PB_EINVAL, "stream must be 0 or 1");
+    if (int rc = check_fine_grained(h)) return rc;
     if (codes) *codes = h->d_codes + ((size_t)ant * 2 + stream) * h->S * h->trim;
     if (ave) {
         *ave = h->d_ave ? h->d_ave + ((size_t)ant * 2 + stream) * h->S * h->ave_per_seg : nullptr;
@@ -1196,6 +1205,7 @@ extern "C" int pb_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumula
     if (!h || !d_sum) return PB_EINVAL;
     if (!h->cfg.keep_ave) return fail(h, PB_ESTATE, "pb_coadd_local needs keep_ave=1");
     if (nseg < 1 || nseg > h->S) return fail(h, PB_EINVAL, "pb_coadd_local: nseg out of range");
+    if (int rc = check_fine_grained(h)) return rc;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     // The fp32 planes come from this set's detect, which may have run on the second stream.  On a
     // coadd stream of its own (pb_set_coadd_stream) this wait holds up neither the next batch's
@@ -1233,6 +1243,7 @@ extern "C" int pb_coadd_local_codes(pb_handle *h, int nseg, float *d_sum, int ac
     if (!h || !d_sum) return PB_EINVAL;
     if (nseg < 1 || nseg > h->S) return fail(h, PB_EINVAL, "pb_coadd_local_codes: nseg out of range");
     if (nseg > h->processed) return fail(h, PB_EINVAL, "pb_coadd_local_codes: more segments than the batch holds");
+    if (int rc = check_fine_grained(h)) return rc;
     if (h->d_coadd_target && d_sum == h->d_coadd_target)
         return fail(h, PB_ESTATE, "pb_coadd_local_codes: d_sum is the set's fp32 coadd target");
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1240,6 +1251,71 @@ extern "C" int pb_coadd_local_codes(pb_handle *h, int nseg, float *d_sum, int ac
     if (hipEventQuery(h->ev_chan) != hipSuccess) HIPCHK(h, hipStreamWaitEvent(cs, h->ev_chan, 0));
     hipError_t e = launch_coadd_local_codes(h, nseg, d_sum, accumulate, cs);
     if (e == hipSuccess) e = hipEventRecord(h->ev_cl, cs);      // (the set's next detect writes codes and planes alike)
+    HIPCHK(h, e);
+    return PB_OK;
+}
+
+// The incoherent sum in the defined order (coadd_tree.hip): one rank's node of the tree from
+// the selected set's fp32 planes, ordered against detect and the set's next batch exactly like pb_coadd_local.
+extern "C" int pb_coadd_local_tree(pb_handle *h, int nseg, const int32_t *ant_order, int n, float *d_dst)
+{
+    if (!h || !d_dst || !ant_order) return PB_EINVAL;
+    if (!h->cfg.keep_ave) return fail(h, PB_ESTATE, "pb_coadd_local_tree needs keep_ave=1");
+    if (nseg < 1 || nseg > h->S) return fail(h, PB_EINVAL, "pb_coadd_local_tree: nseg out of range");
+    if (nseg > h->processed) return fail(h, PB_EINVAL, "pb_coadd_local_tree: more segments than the batch holds");
+    if (int rc = check_fine_grained(h)) return rc;
+    if (n < 1 || n > PB_COADD_MAX_LEAVES) return fail(h, PB_EINVAL, "pb_coadd_local_tree: 1..PB_COADD_MAX_LEAVES leaves");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int stream = h->cfg.rfi_mode == 0 ? 0 : 1;
+    const float *leaves[PB_COADD_MAX_LEAVES];
+    for (int i = 0; i < n; ++i) {
+        const int a = ant_order[i];
+        if (a < 0 || a >= h->A) return fail(h, PB_EINVAL, "pb_coadd_local_tree: antenna index out of range");
+        leaves[i] = (h->d_coadd_target && a == 0) ? h->d_coadd_target
+                                                  : h->d_ave + ((size_t)a * 2 + stream) * h->S * h->ave_per_seg;
+        if (leaves[i] == d_dst && n > 1) return fail(h, PB_EINVAL, "pb_coadd_local_tree: d_dst is one of the leaves");
+    }
+    hipStream_t cs = h->s_coadd ? h->s_coadd : h->stream;
+    if (hipEventQuery(h->ev_chan) != hipSuccess) HIPCHK(h, hipStreamWaitEvent(cs, h->ev_chan, 0));
+    if (n == 1 && leaves[0] == d_dst) return PB_OK;       // (a coadd target: detect wrote the leaf where it is wanted;
+                                                          //  pb_coadd_release books the "planes consumed" event)
+    hipStream_t s_main = h->stream;
+    h->stream = cs;                       // (StageTimer records on h->stream)
+    hipError_t e;
+    {
+        StageTimer t(h, PB_ST_COADD);
+        e = launch_coadd_tree(leaves, n, d_dst, (size_t)nseg * h->ave_per_seg, cs);
+        t.stop();
+    }
+    if (e == hipSuccess) e = hipEventRecord(h->ev_cl, cs);
+    h->stream = s_main;
+    HIPCHK(h, e);
+    return PB_OK;
+}
+
+// The root's part: T_n over the gathered partial sums (caller-owned planes), on the coadd stream.
+extern "C" int pb_coadd_tree(pb_handle *h, const float *const *d_leaves, int n, float *d_dst, size_t nfloat)
+{
+    if (!h || !d_leaves || !d_dst) return PB_EINVAL;
+    if (n < 1 || n > PB_COADD_MAX_LEAVES) return fail(h, PB_EINVAL, "pb_coadd_tree: 1..PB_COADD_MAX_LEAVES leaves");
+    if (nfloat & 3) return fail(h, PB_EINVAL, "pb_coadd_tree: nfloat must be a multiple of 4");
+    for (int i = 0; i < n; ++i) {
+        if (!d_leaves[i] || ((uintptr_t)d_leaves[i] & 15)) return fail(h, PB_EINVAL, "pb_coadd_tree: leaf null or not 16-byte aligned");
+        if (d_leaves[i] == d_dst && n > 1) return fail(h, PB_EINVAL, "pb_coadd_tree: d_dst is one of the leaves");
+    }
+    if ((uintptr_t)d_dst & 15) return fail(h, PB_EINVAL, "pb_coadd_tree: d_dst not 16-byte aligned");
+    if (n == 1 && d_leaves[0] == d_dst) return PB_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t cs = h->s_coadd ? h->s_coadd : h->stream;
+    hipStream_t s_main = h->stream;
+    h->stream = cs;
+    hipError_t e;
+    {
+        StageTimer t(h, PB_ST_COADD);
+        e = launch_coadd_tree(d_leaves, n, d_dst, nfloat, cs);
+        t.stop();
+    }
+    h->stream = s_main;
     HIPCHK(h, e);
     return PB_OK;
 }

@@ -102,7 +102,6 @@ struct pb_handle {
     std::vector<std::vector<uint32_t>> ready_epoch;   // [set][seg] batches that segment slot of the set has seen
     int chunk_rows;                                    // detect's chunk: 32 rows, 8 when R is not a multiple of 32
     int fuse;                                          // PB_FUSE_KURTOSIS at pb_create (pb_fused_kurtosis)
-    std::vector<uint32_t> pfb_epoch;                   // per buffer set: launches of k_channelize_pfb_kur on it, 1..31 (the look-back words' epoch)
     uint32_t *d_fg_error;                              // a detect workgroup gave up waiting for a row (must stay 0)
     std::vector<BufSet> sets;
     int cur_set;
@@ -140,6 +139,11 @@ bool pb_fused_kurtosis(const pb_handle *h);
 #ifndef PB_FG
 #define PB_FG 0
 #endif
+// PB_EXPERIMENTS: the experiments build (libpb_hip_exp.so, `make exp`) also reads PB_SKIP, which leaves kernels out
+// (results invalid; energy and upper-bound measurements).  Never in the shipped library.
+#ifndef PB_EXPERIMENTS
+#define PB_EXPERIMENTS 0
+#endif
 // detect runs beside the channeliser of its OWN batch, chunk by chunk behind it (row-ready counters), instead of
 // after it: the fused in-library-FFT path with two or more buffer sets, one antenna per handle, at most 16 segments
 // per call.  An experiment that is bit-exact but did not pay (profiles/r04_notes.md): only in the PB_FG build, where
@@ -166,5 +170,6 @@ hipError_t launch_pfb_weights(pb_handle *h, int nseg);
 hipError_t launch_pfb_history(pb_handle *h, int nseg);   // taps = 4: behind the weights, into the history slot the batch does not read
 hipError_t launch_channelize_f32(pb_handle *h, const float *d_x, int nrows, int taps, float2 *d_out);
 hipError_t launch_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate, hipStream_t st);
+hipError_t launch_coadd_tree(const float *const *leaves, int n, float *d_dst, size_t nfloat, hipStream_t st);
 hipError_t launch_coadd_digitise(pb_handle *h, int nseg, const float *d_sum, float scale,
                                  uint8_t *d_codes, hipStream_t st);
