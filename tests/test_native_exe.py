@@ -183,19 +183,82 @@ def test_native_cmd_quit(tmp_path):
     assert "Received CMD_QUIT, indicating data taking is ceasing.  Exiting." in log
 
 
-def test_ring_keys_reach_the_shim(tmp_path):
+def test_ring_keys_reach_the_shim(tmp_path, psrdada_mock):
     """`-k 40` without --replay goes to the psrdada shim (dlopen at run time): without the library the program says
-    what to build; with a library exporting the shim's symbols (the in-memory mock, in which no ring 0x40 exists
-    in this process) it binds all of them and reports the failed connect.  No GPU is touched before the rings
-    are connected."""
+    what to build; with the REAL shim (built over the psrdada stand-in of tests/mock_psrdada; no ring 0x40 exists) it
+    binds all nine symbols and reports the failed connect.  No GPU is touched before the rings are connected."""
     env = dict(os.environ, PB_DADA_LIB=str(tmp_path / "nope.so"))
     r = _run(["-k", "40", "-b", "8", "--logdir", str(tmp_path), "-o", "--no-control"], env=env)
     assert r.returncode == 1 and b"psrdada rings need the shim library" in r.stdout
-    src = os.path.join(ROOT, "tests", "mock_dada", "pb_dada_mock.c")
-    so = str(tmp_path / "libmock.so")
-    subprocess.run(["gcc", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-o", so, src], check=True)
-    r = _run(["-k", "40", "-b", "8", "--logdir", str(tmp_path), "-o", "--no-control"], env=dict(os.environ, PB_DADA_LIB=so))
+    env = dict(os.environ, PB_DADA_LIB=psrdada_mock.shim_path, MOCK_PSRDADA_DIR=str(tmp_path))
+    r = _run(["-k", "40", "-b", "8", "--logdir", str(tmp_path), "-o", "--no-control"], env=env)
     assert r.returncode == 1 and b"could not connect to input ring 40" in r.stdout and b"lacks symbols" not in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", ["8", "1"])
+def test_native_host_on_rings_equals_replay(tmp_path, psrdada_mock, threads):
+    """`process_baseband -k 40 -K 42 -C 46` (scripts/start_process:50) as its own PROCESS on three rings, through the
+    real shim (block-level reads with 8 copy threads / the reference's ipcio_read with PB_DADA_THREADS=1): a writer
+    (this process, tools/dump_to_ring.py's calls) has filled ring 40 with a 13-s dump; afterwards the .fil files equal
+    those of a --replay of the same dump, ring 46 holds every segment of the excised stream and ring 42 the 10-s-then-
+    1-s writes.  The rings are the stand-in's (shared files): the shim's logic and the host's ring code are what is
+    exercised, not psrdada."""
+    from helpers import make_input
+    dada = importlib.import_module("vlite-fast_amd.dada")
+    nsec = 13
+    data = make_input(19, R, nsec * SEG)
+    dump = str(tmp_path / "obs.uw")
+    _dump(dump, data, drop={(1, 57), (2, 0)})
+    (tmp_path / "replay").mkdir()
+    r = _run(_argv(tmp_path / "replay", dump, 8))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    fps = R * SEG * 12500 // 5000
+    trim = 2 * R * 4096 // 16
+    ctl, keys = psrdada_mock.ctl, ((0x40, 2 * fps * 5032, 16), (0x42, 10 * SEG * trim, 8), (0x46, trim, 256))
+    rdir = tmp_path / "rings"
+    rdir.mkdir()
+    old = os.environ.get("MOCK_PSRDADA_DIR")
+    os.environ["MOCK_PSRDADA_DIR"] = str(rdir)
+    try:
+        for key, bufsz, nbufs in keys:
+            assert ctl.mock_psrdada_create(key, bufsz, nbufs) == 0
+        raw = open(dump, "rb").read()
+        w = dada.PsrdadaRing(0x40, "w", lib=psrdada_mock.shim)
+        w.write_header(raw[:4096])
+        w.write(np.frombuffer(raw[4096:], np.uint8))
+        w.end_of_data()
+        w.close()
+        ctl.mock_psrdada_shutdown(0x40)
+        (tmp_path / "ring").mkdir()
+        env = dict(os.environ, PB_DADA_LIB=psrdada_mock.shim_path, PB_DADA_THREADS=threads)
+        r = _run(["-k", "40", "-K", "42", "-C", "46", "-w", "2", "-b", "8", "-P", "1", "-r", "2", "-g", "0", "--datadir",
+                  str(tmp_path / "ring"), "--logdir", str(tmp_path / "ring" / "logs"), "--no-control", "--rows-per-seg", str(R)], env=env)
+        assert r.returncode == 0, (r.stdout.decode()[-2000:], r.stderr.decode()[-2000:])
+        names = sorted(p.name for p in (tmp_path / "replay").glob("*.fil"))
+        assert len(names) == 2
+        for n in names:
+            assert (tmp_path / "ring" / n).read_bytes() == (tmp_path / "replay" / n).read_bytes(), n
+        kur = (tmp_path / "replay" / names[1]).read_bytes()
+        hl = len(sigproc.sigproc_header(7, 0.8718, -0.72452, "B0833-45", 57570 + 3600 / 86400., 1, 8))
+        co = dada.PsrdadaRing(0x46, "r", lib=psrdada_mock.shim)
+        ch = vdif.ascii_header_parse(co.next_header())
+        assert ch["SIGPROC_FILE"].endswith("_muos_ea99_kur.fil")
+        assert co.read(len(kur)) == kur[hl:]
+        co.close()
+        out = dada.PsrdadaRing(0x42, "r", lib=psrdada_mock.shim)
+        assert vdif.ascii_header_parse(out.next_header())["SIGPROC_FILE"].endswith("_muos_ea07_kur.fil")
+        assert out.read(len(kur)) == kur[hl:]
+        out.close()
+        nb = (len(raw) - 4096) // (2 * fps * 5032) + 1           # full one-second buffers + the end-of-data one
+        assert psrdada_mock.counts(0x40)[:2] == (nb, nb)         # the host has handed every buffer back
+    finally:
+        for key, _, _ in keys:
+            ctl.mock_psrdada_destroy(key)
+        if old is None:
+            os.environ.pop("MOCK_PSRDADA_DIR", None)
+        else:
+            os.environ["MOCK_PSRDADA_DIR"] = old
 
 
 @pytest.mark.gpu
