@@ -92,6 +92,16 @@ def _cpu_chunk(arg):
     return hi - lo
 
 
+def _cpu_pfb_chunk(arg):
+    p, i, n = arg
+    import oracle as O
+    nwin = _CPU_V.shape[1] // (4 * NFFT) - 1            # windows of 4 x 12500 samples that yield spectra
+    lo, hi = nwin * i // n, nwin * (i + 1) // n
+    if hi > lo:                                          # windows [lo, hi) -> 4 (hi - lo) spectra, the same ones
+        O.polyphase_filterbank(_CPU_V[p, lo * 4 * NFFT:(hi + 1) * 4 * NFFT], nchan=NFFT // 2, nwindow=4)
+    return 4 * (hi - lo)
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -139,6 +149,29 @@ def cpu_baseline():
         pool.map(_cpu_chunk, chunks)
     t4 = time.perf_counter()
     allc = nsamp / ((t4 - t3) + (t1 - t0)) / 1e6   # the deframe pass is not parallelised
+    # P2, the CPU baseline north_star names for the PFB mode: analysis/baseband.py:1207-1237 polyphase_filterbank
+    # (restated in oracle/oracle.py, pinned to the imported reference by tests/golden) with nchan = 6250, nwindow = 4 --
+    # the window the taps = 4 GPU path applies -- on the same deframed second: one core, then the windows split over
+    # the pool.  It yields complex spectra (no detection), 4 per 50 000-sample window, 10 236 per pol and second.
+    pfb = None
+    try:
+        t7 = time.perf_counter()
+        nspec = sum(O.polyphase_filterbank(v[p], nchan=NFFT // 2, nwindow=4).shape[0] for p in range(2))
+        t8 = time.perf_counter()
+        with mp.get_context("fork").Pool(ncores) as pool:
+            nspec_pool = sum(pool.map(_cpu_pfb_chunk, chunks))
+        t9 = time.perf_counter()
+        assert nspec_pool == nspec, (nspec_pool, nspec)
+        pfb_one = nsamp / ((t8 - t7) + (t1 - t0)) / 1e6
+        pfb_all = nsamp / ((t9 - t8) + (t1 - t0)) / 1e6
+        pfb = {"value": round(pfb_all, 2), "unit": "Msamp/s", "cores": ncores, "kind": "port", "value_1core": round(pfb_one, 2),
+               "x_realtime": round(pfb_all / 128.0, 4), "x_realtime_1core": round(pfb_one / 128.0, 4), "cpu_model": cpu_model(),
+               "sample": "BASELINE configs[0]'s second (1.0 s of one antenna, dual-pol, deframed as above): NumPy "
+                         "polyphase_filterbank(nchan=6250, nwindow=4) (analysis/baseband.py:1207-1237 restated), %d complex "
+                         "spectra; 1 core (%.1f s), and the windows split over a %d-process pool (%.1f s)"
+                         % (nspec, t8 - t7, ncores, t9 - t8)}
+    except Exception as e:
+        pfb = {"error": repr(e)[:200]}
     _CPU_V = None
     # ... and the hot path itself -- the oracle's C restatement of the reference's kernels K1-K11 (convertarray,
     # kurtosis, D'Agostino, apply, 12500-point FFT, detect/normalise, scrunch, requantise; oracle/pb_oracle.c) -- on four
@@ -159,7 +192,7 @@ def cpu_baseline():
                          "RFI mode 2, both output streams, 8-bit, one core" % (nseg_cpu, t6 - t5)}
     except Exception as e:      # (the baseline is a reported figure: never the reason a bench run fails)
         hot = {"error": repr(e)[:200]}
-    return {"value": round(allc, 2), "unit": "Msamp/s", "cores": ncores, "kind": "port", "hot_path": hot,
+    return {"value": round(allc, 2), "unit": "Msamp/s", "cores": ncores, "kind": "port", "hot_path": hot, "pfb": pfb,
             "value_1core": round(one, 2), "x_realtime": round(allc / 128.0, 4), "cpu_model": cpu_model(),
             "sample": "BASELINE configs[0]: 1.0 s of one antenna, dual-pol, 51 200 VDIF frames: deframe + NumPy "
                       "|rfft(12500)|^2 over 20 480 rows (analysis/baseband.py:filterbank restated); 1 core, and the "
@@ -830,6 +863,8 @@ def main():
                             "roofline": dict(t4["roofline"], alone=alone_record(torch, lp, args, dev, local, 4)),
                             "stage_ms_per_step": t4["stage_ms_per_step"],
                             "note": "4-tap Hamming WOLA window (analysis/baseband.py:1207-1237) in the streaming path"}
+            if cpu is not None and cpu.get("pfb") is not None:
+                out["taps4"]["cpu_baseline"] = cpu.pop("pfb")       # P2 timed beside the mode it is the baseline of
             ing = run_chain(torch, dist, lp, args, dev, local, rank, world, 1, nsub, min(args.warmup, 5), ingest=True, regions=1)
             gbs = 2 * (S * ing_frames(S) * 5032) / (ing["ms_per_step"] * 1e-3) / 1e9
             out["ingest"] = {"ms_per_step": round(ing["ms_per_step"], 4), "value": round(ing["msamp"], 1), "unit": "Msamp/s",

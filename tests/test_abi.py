@@ -77,11 +77,11 @@ def test_shipped_library_holds_no_result_invalidating_switch():
             assert name not in blob, "%s contains %s" % (fn, name.decode())
     # and the sources read the environment only through names on this list
     allowed = {"PB_LEAN_LDS", "PB_COPY_DMA", "PB_COPY_WGS", "PB_DETECT_DEPTH", "PB_FINE_GRAINED", "PB_OVERLAP_DETECT",
-               "PB_DET_CUS", "PB_DET_PRIO", "PB_FUSE_KURTOSIS", "PB_KUR_EARLY", "PB_SKIP"}
+               "PB_DET_CUS", "PB_DET_PRIO", "PB_FUSE_KURTOSIS", "PB_KUR_EARLY", "PB_DAG_BANDS", "PB_SKIP"}
     seen = set()
     for fn in os.listdir(csrc):
         if fn.endswith((".hip", ".h")):
-            seen |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(os.path.join(csrc, fn)).read()))
+            seen |= set(re.findall(r'(?:getenv|env_int)\("([A-Z0-9_]+)"', open(os.path.join(csrc, fn)).read()))
     assert seen <= allowed, seen - allowed
     txt = open(os.path.join(csrc, "pb_api.hip")).read()
     i = txt.index('getenv("PB_SKIP")')

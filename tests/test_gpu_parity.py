@@ -72,6 +72,35 @@ def test_prefft_statistics_and_flags_exact(oracle, data, oracle_mode2):
     assert (w == 0).any() and ((w > 0) & (w < 1)).any()
 
 
+@pytest.mark.parametrize("backend", ["hipfft", "lds"])
+def test_flags_exact_without_the_located_crossings(oracle, data, oracle_mode2, monkeypatch, backend):
+    """PB_DAG_BANDS=0 forces the fallback pb_create takes when it cannot bracket the score's crossings (host and device
+    disagreeing): every flag is then decided by the score itself.  Flags, weights and codes are still the oracle's --
+    in the kurtosis kernel (statistics kept) and in the channeliser that flags its own rows."""
+    lp = libpb()
+    monkeypatch.setenv("PB_DAG_BANDS", "0")
+    res, _, _ = oracle_mode2
+    if backend == "hipfft":
+        g = _run_gpu(lp, data, lp.FFT_HIPFFT)
+        for s in range(NSEG):
+            nb = g["flags"][s].size
+            assert np.array_equal(g["flags"][s], (res[s].dag[:nb] > 3.0).astype(np.uint8))
+            assert _same_bits(g["weights"][s * R:(s + 1) * R], res[s].weights[:R])
+    with lp.PbHandle(nant=1, nbit=8, rfi_mode=2, rows_per_seg=R, max_seg=NSEG) as h:
+        _, _, bands = h.dag_check(2.0, 2.001)
+        assert bands[0] == 0 and np.isinf(bands[1]) and bands[2] == 0 and np.isinf(bands[3])     # no crossings in use
+        for s in range(NSEG):
+            h.submit_planar(0, s, data[s, 0], data[s, 1])
+        h.process(NSEG)
+        out = h.fetch(0, 0, NSEG, weights=True)
+    assert np.array_equal(out["kur"], np.concatenate([r.codes_kur for r in res]))
+    assert np.array_equal(out["raw"], np.concatenate([r.codes_raw for r in res]))
+    monkeypatch.delenv("PB_DAG_BANDS")
+    with lp.PbHandle(nant=1, rows_per_seg=8, max_seg=1) as h:
+        _, _, bands = h.dag_check(2.0, 2.001)
+        assert 0 < bands[0] < bands[1] < bands[2] < bands[3] < np.inf
+
+
 def test_block_kurtosis_row_statistic(oracle, data, oracle_mode2):
     """K4: block_kurtosis + compute_dagostino2 (src/pb_kernels.cu:140-241), the per-FFT-row statistic the
     reference computes and no output uses; kept with debug_keep and bit-exact against the oracle."""

@@ -88,11 +88,10 @@ __global__ __launch_bounds__(256) void k_copy_out(uint4 *__restrict__ dst, const
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
-hipError_t launch_copy_out(uint8_t *host_pinned, const uint8_t *dev, size_t nbytes, hipStream_t st)
+hipError_t launch_copy_out(const PbSched &sched, uint8_t *host_pinned, const uint8_t *dev, size_t nbytes, hipStream_t st)
 {
     if (nbytes == 0) return hipSuccess;
-    static const int use_dma = getenv("PB_COPY_DMA") ? atoi(getenv("PB_COPY_DMA")) : 0;    // timing experiments
-    if (use_dma || (nbytes & 15) || ((uintptr_t)host_pinned & 15) || ((uintptr_t)dev & 15))
+    if (sched.copy_dma || (nbytes & 15) || ((uintptr_t)host_pinned & 15) || ((uintptr_t)dev & 15))
         return hipMemcpyAsync(host_pinned, dev, nbytes, hipMemcpyDeviceToHost, st);
     void *dptr = nullptr;
     hipError_t e = hipHostGetDevicePointer(&dptr, host_pinned, 0);
@@ -100,8 +99,7 @@ hipError_t launch_copy_out(uint8_t *host_pinned, const uint8_t *dev, size_t nbyt
     const size_t n16 = nbytes >> 4;
     // 8 workgroups saturate PCIe (10 MB in ~0.2 ms); more only hold store queues of more CUs full,
     // which slows the channeliser running beside them (32: +10 % on the step).  PB_COPY_WGS overrides.
-    static const int maxb = getenv("PB_COPY_WGS") ? atoi(getenv("PB_COPY_WGS")) : 8;
-    const unsigned nb = (unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)maxb);
+    const unsigned nb = (unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)(sched.copy_wgs > 0 ? sched.copy_wgs : 8));
     k_copy_out<<<nb, 256, 0, st>>>((uint4 *)dptr, (const uint4 *)dev, n16);
     return hipGetLastError();
 }

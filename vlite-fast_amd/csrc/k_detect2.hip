@@ -636,7 +636,7 @@ hipError_t launch_detect_pow(pb_handle *h, int nseg, bool fine_grained)
     dim3 grid(PB_NCHANOUT / 32, h->cfg.rfi_mode == 2 ? 2 : 1, h->A);
     // three chunks in flight where detect runs wholly beside the next batch's channeliser (it flags its own rows and
     // starts straight behind the previous one), two otherwise (measured both ways, see the comment on DEPTH)
-    static const int depth_env = getenv("PB_DETECT_DEPTH") ? atoi(getenv("PB_DETECT_DEPTH")) : 0;   // 2 / 3: timing experiments
+    const int depth_env = h->sched.detect_depth;     // PB_DETECT_DEPTH 2 / 3: timing experiments
     const bool deep = depth_env ? depth_env == 3
                                 : (D2_DEPTH_OVERLAPPED == 3 && pb_fused_kurtosis(h) && h->cfg.taps == 1 && h->sets.size() >= 2 && h->A == 1);
     if (h->R % 32 == 0) {

@@ -54,6 +54,26 @@ static inline int pb_skip_mask()
 #endif
 }
 
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+PbSched pb_read_sched()
+{
+    PbSched s;
+    s.overlap_detect = env_int("PB_OVERLAP_DETECT", 1);
+    s.kur_early = env_int("PB_KUR_EARLY", 1);
+    s.fine_grained = env_int("PB_FINE_GRAINED", 1);
+    s.detect_depth = env_int("PB_DETECT_DEPTH", 0);
+    s.copy_dma = env_int("PB_COPY_DMA", 0);
+    s.copy_wgs = env_int("PB_COPY_WGS", 8);
+    s.det_cus = env_int("PB_DET_CUS", 0);
+    s.det_prio = env_int("PB_DET_PRIO", 1);
+    return s;
+}
+
 bool pb_fused_kurtosis(const pb_handle *h)
 {
     // h->fuse (PB_FUSE_KURTOSIS when the handle was created): 0 never, 1 (default) the rectangular window.  taps = 4
@@ -70,9 +90,8 @@ bool pb_fine_grained(const pb_handle *h)
     // slower -- 0.647 - 0.655 against 0.632 ms per step in 40-step regions on the same box (profiles/r04_notes.md):
     // detect's workgroups of batch k + 1 can only start when batch k's have all left, by then the channeliser has taken
     // their places, and a detect that trickles in over 0.3 ms no longer has a step's slack to finish in.
-    static const int allow = PB_FG && (getenv("PB_FINE_GRAINED") ? atoi(getenv("PB_FINE_GRAINED")) : 1);
-    static const int overlap_detect = getenv("PB_OVERLAP_DETECT") ? atoi(getenv("PB_OVERLAP_DETECT")) : 1;
-    return allow && overlap_detect && pb_fused_kurtosis(h) && h->cfg.taps == 1 && h->sets.size() >= 2 && h->A == 1 && h->S <= PB_FG_MAXSEG &&
+    const int allow = PB_FG && h->sched.fine_grained;
+    return allow && h->sched.overlap_detect && pb_fused_kurtosis(h) && h->cfg.taps == 1 && h->sets.size() >= 2 && h->A == 1 && h->S <= PB_FG_MAXSEG &&
            h->d_ready != nullptr;
 }
 
@@ -305,15 +324,14 @@ static int create_impl(pb_handle *h)
         HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
         // timing experiments: PB_DET_CUS=n confines detect to n CUs of every 32 (a CU mask on its stream), so that
         // its workgroups pack three to a CU there instead of taking one channeliser slot on every CU
-        const int det_cus = getenv("PB_DET_CUS") ? atoi(getenv("PB_DET_CUS")) : 0;
+        const int det_cus = h->sched.det_cus;
         if (det_cus > 0 && det_cus < 32) {
             uint32_t mask[8];
             for (int i = 0; i < 8; ++i) mask[i] = (1u << det_cus) - 1u;
             HIPCHK(h, hipExtStreamCreateWithCUMask(&h->s_det, 8, mask));
         } else {
             // (PB_DET_PRIO=0: detect's stream at the default priority; timing experiments)
-            static const int det_hi = getenv("PB_DET_PRIO") ? atoi(getenv("PB_DET_PRIO")) : 1;
-            HIPCHK(h, hipStreamCreateWithPriority(&h->s_det, hipStreamNonBlocking, det_hi ? hi : lo));
+            HIPCHK(h, hipStreamCreateWithPriority(&h->s_det, hipStreamNonBlocking, h->sched.det_prio ? hi : lo));
         }
     }
     HIPCHK(h, hipStreamCreateWithFlags(&h->s_kur, hipStreamNonBlocking));
@@ -423,13 +441,24 @@ static int create_impl(pb_handle *h)
     }
     h->dag = make_dag((float)PB_NKURTO);
     h->dag_fb = make_dag((float)PB_NFFT);
-    if (int rcb = find_dag_bands(h, h->dag)) {
+    h->dag_bands = 0;
+    if (env_int("PB_DAG_BANDS", 1) == 0) {
+        // (test hook: the fallback below on purpose -- tests/test_gpu_parity.py checks that the flags stay bit-exact)
+        h->dag_bands = -1;
+    } else if (int rcb = find_dag_bands(h, h->dag)) {
         // The bands only save work (the score is then evaluated in a few floats around the crossings instead of
         // everywhere): if the search does not bracket the crossings -- host and device disagreeing by more than the
-        // scanned window -- fall back to "no bands", where the score itself decides every flag.  A HIP error is fatal.
+        // scanned window -- fall back to "no bands", where the score itself decides every flag: same flags, more
+        // arithmetic.  That disagreement is worth knowing about on a library pinned bit for bit: it is said once on
+        // stderr and kept in the handle (pb_debug_dag_check reports the bands as 0, inf, 0, inf).  A HIP error is fatal.
         if (rcb != PB_ESTATE) return rcb;
+        fprintf(stderr, "libpb_hip: warning: %s -- flag decision falls back to evaluating the D'Agostino score for "
+                        "every block (results unchanged, kurtosis statistic slower)\n", h->err.c_str());
         h->dag = make_dag((float)PB_NKURTO);
+        h->dag_bands = -2;
         h->err.clear();
+    } else {
+        h->dag_bands = 1;
     }
     // (a copy in device memory for the channeliser that flags its own rows: ten fewer scalar registers of arguments)
     HIPCHK(h, hipMalloc((void **)&h->d_dag, sizeof(DagConsts)));
@@ -459,7 +488,8 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
 
     pb_handle *h = new pb_handle();
     h->cfg = c;
-    h->fuse = getenv("PB_FUSE_KURTOSIS") ? atoi(getenv("PB_FUSE_KURTOSIS")) : 1;
+    h->fuse = env_int("PB_FUSE_KURTOSIS", 1);
+    h->sched = pb_read_sched();
     h->R = c.rows_per_seg;
     h->S = c.max_seg;
     h->A = c.nant;
@@ -959,8 +989,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
             // set's flags and weights are still being read by the previous batch's channeliser's successor, detect,
             // until ev_chan; the wait for the channeliser keeps the kurtosis pass beside that detect.
             // PB_KUR_EARLY=0 restores the wait.
-            static const int kur_early = getenv("PB_KUR_EARLY") ? atoi(getenv("PB_KUR_EARLY")) : 1;
-            if (!(kur_early && h->sets.size() >= 3)) e = hipStreamWaitEvent(h->s_kur, h->ev_fftdone, 0);
+            if (!(h->sched.kur_early && h->sets.size() >= 3)) e = hipStreamWaitEvent(h->s_kur, h->ev_fftdone, 0);
             if (e == hipSuccess) e = hipStreamWaitEvent(h->s_kur, h->ev_chan, 0);  // flags / weights of this set free (its detect is done)
             h->stream = h->s_kur;
         } else if (h->sets.size() >= 2 && (h->staged || !fused)) {
@@ -1010,8 +1039,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
     // Row-ready counters: this batch brings every segment slot it uses one epoch further (the channeliser adds one per
     // finished row, detect waits for chunk_rows x epoch).  Booked before either kernel is queued.
     // (PB_FINE_GRAINED=2, timing experiments: the channeliser signals its rows, detect still waits for the event)
-    static const int fg_mode = getenv("PB_FINE_GRAINED") ? atoi(getenv("PB_FINE_GRAINED")) : 1;
-    const bool fine = pb_fine_grained(h) && (int)h->sets.size() >= 2 && fg_mode != 2;
+    const bool fine = pb_fine_grained(h) && (int)h->sets.size() >= 2 && h->sched.fine_grained != 2;
     if (fine)
         for (int i = 0; i < nseg; ++i) h->ready_epoch[h->cur_set][i] += 1;
     if (hipfft) {
@@ -1038,8 +1066,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
     // bandpass wave (one 48 KB workgroup per CU), the channeliser VALU-bound: side by side the step is
     // ~9 % shorter than back to back (0.915 vs 1.007 ms per second of data; PB_OVERLAP_DETECT=0 turns
     // it off).  With one buffer set everything stays on one stream.
-    static const int overlap_detect = getenv("PB_OVERLAP_DETECT") ? atoi(getenv("PB_OVERLAP_DETECT")) : 1;
-    if (overlap_detect && h->sets.size() >= 2 && !hipfft) {
+    if (h->sched.overlap_detect && h->sets.size() >= 2 && !hipfft) {
         hipStream_t s_main = h->stream;
         // Fine-grained: detect of THIS batch starts beside its channeliser and follows it chunk by chunk (row-ready
         // counters), so it does not wait for the channeliser's end: a batch's filterbank bytes are complete shortly
@@ -1062,7 +1089,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
             for (int st = 0; st < 2 && e2 == hipSuccess; ++st) {
                 if (st == 0 ? h->cfg.rfi_mode == 1 : h->cfg.rfi_mode == 0) continue;
                 const size_t o = ((size_t)a * 2 + st) * h->S * h->trim;
-                e2 = launch_copy_out(h->h_codes + o, h->d_codes + o, (size_t)nseg * h->trim, h->s_copy);
+                e2 = launch_copy_out(h->sched, h->h_codes + o, h->d_codes + o, (size_t)nseg * h->trim, h->s_copy);
             }
         if (e2 == hipSuccess) e2 = hipEventRecord(h->ev_det, h->s_copy);
         if (e2 == hipSuccess) e2 = hipEventRecord(h->ev_alldone, h->s_copy);
@@ -1086,7 +1113,7 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         for (int st = 0; st < 2 && e == hipSuccess; ++st) {
             if (st == 0 ? h->cfg.rfi_mode == 1 : h->cfg.rfi_mode == 0) continue;
             const size_t o = ((size_t)a * 2 + st) * h->S * h->trim;
-            e = launch_copy_out(h->h_codes + o, h->d_codes + o, (size_t)nseg * h->trim, h->s_det);
+            e = launch_copy_out(h->sched, h->h_codes + o, h->d_codes + o, (size_t)nseg * h->trim, h->s_det);
         }
     if (e == hipSuccess) e = hipEventRecord(h->ev_det, h->s_det);
     HIPCHK(h, e);
@@ -1364,7 +1391,7 @@ extern "C" int pb_coadd_finish(pb_handle *h, int nseg, const float *d_sum, int n
     // ago, went through the same stream)
     hipStream_t cs = h->s_coadd ? h->s_coadd : h->stream;
     HIPCHK(h, launch_coadd_digitise(h, nseg, d_sum, scale, h->d_coadd_codes + slot * nb, cs));
-    HIPCHK(h, launch_copy_out(h->h_coadd_codes + slot * nb, h->d_coadd_codes + slot * nb, (size_t)nseg * h->trim, cs));
+    HIPCHK(h, launch_copy_out(h->sched, h->h_coadd_codes + slot * nb, h->d_coadd_codes + slot * nb, (size_t)nseg * h->trim, cs));
     HIPCHK(h, hipEventRecord(h->ev_coadd[slot], cs));
     if (codes_host) {
         HIPCHK(h, hipEventSynchronize(h->ev_coadd[slot]));

@@ -42,8 +42,24 @@ struct FftTables {
     float2 *taps_n; // the same interleaved for the PFB channeliser: [6250 n][4 taps] pairs (samples 2n, 2n+1)
 };
 
+// Scheduling choices read from the environment ONCE PER HANDLE, at pb_create (INTEGRATION.md lists them).  None of
+// them changes a result: tests/test_gpu_schedules.py runs one full-size second through their combinations and
+// requires identical bytes.  (Per handle, not per process: a test -- or a host -- can hold handles of several modes.)
+struct PbSched {
+    int overlap_detect;   // PB_OVERLAP_DETECT (1): detect + copy-out on streams of their own beside the next batch
+    int kur_early;        // PB_KUR_EARLY (1): >= 3 sets: the kurtosis pass does not wait for the previous channeliser
+    int fine_grained;     // PB_FINE_GRAINED (1; only in the PB_FG build): 0 off, 1 on, 2 signal rows but wait for the event
+    int detect_depth;     // PB_DETECT_DEPTH (0 = by configuration): 2 / 3 chunks in flight in detect's ring
+    int copy_dma;         // PB_COPY_DMA (0): 1 = hipMemcpyAsync instead of the copy-out kernel
+    int copy_wgs;         // PB_COPY_WGS (8): workgroups of the copy-out kernel
+    int det_cus;          // PB_DET_CUS (0): CU mask of the detect stream (timing experiments)
+    int det_prio;         // PB_DET_PRIO (1): detect's stream at the highest priority
+};
+PbSched pb_read_sched();
+
 struct pb_handle {
     pb_config cfg;
+    PbSched sched;
     int R;                 // rows per segment
     int S;                 // max segments
     int A;                 // antennas
@@ -118,6 +134,7 @@ struct pb_handle {
     int coadd_slot, coadd_last;
     FftTables ft;
     DagConsts dag, dag_fb;   // D'Agostino constants for N = 500 (blocks) and N = 12500 (FFT rows, K4)
+    int dag_bands;           // 1: crossings located (flags decided without the cube root); -1: PB_DAG_BANDS=0; -2: search failed, fallback
     DagConsts *d_dag;        // dag in device memory
     std::map<long, hipfftHandle> plans;
 
@@ -163,7 +180,7 @@ hipError_t launch_inject_c64(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_detect(pb_handle *h, int nseg, int inject_now, bool fine_grained = false);
 hipError_t launch_detect_pow(pb_handle *h, int nseg, bool fine_grained = false);
 // device -> pinned host copy done by a kernel (see k_detect.hip: hipMemcpyAsync blocks the host now and then)
-hipError_t launch_copy_out(uint8_t *host_pinned, const uint8_t *dev, size_t nbytes, hipStream_t st);
+hipError_t launch_copy_out(const PbSched &sched, uint8_t *host_pinned, const uint8_t *dev, size_t nbytes, hipStream_t st);
 hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_pfb_weights(pb_handle *h, int nseg);
