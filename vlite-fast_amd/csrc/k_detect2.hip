@@ -50,6 +50,7 @@ struct Detect2Args {
     int target_stream;
     size_t trim, ave_per_seg;
     int S, R, nseg;
+    int ant0;                // blockIdx.z counts antennas from here (one launch per antenna: PbSched::detect_serial)
     float scale, oms, tscale;
     // Fine-grained coupling to the channeliser of the SAME batch, which is still running (pb_internal.h): chunk (seg,
     // rb) of antenna ant may be read once ready[(ant * S + seg) * cps + rb] has reached target[seg]; nullptr: every
@@ -337,7 +338,7 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
     const int cg = blockIdx.x;
     constexpr int stream = KUR ? 1 : 0;
     constexpr int NQ = T / 4, NG = T / PB_NSCRUNCH;
-    const int ant = blockIdx.z;
+    const int ant = a.ant0 + (int)blockIdx.z;
     const int R = a.R, cps = R / T, nchunk = a.nseg * cps;
     const int ntime = R / PB_NSCRUNCH;
     const float *wrow = a.wrow + (size_t)ant * a.S * R;
@@ -452,43 +453,83 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
                 for (int j = 0; j < T; ++j) pk[j] = s_p[slot][j][lane];
                 s_u0[buf][lane] = bp;
                 float t1 = scale * pk[0];
+                // Four rows per asm block, in FIXED registers: the bp after each row goes straight into the quad that the
+                // 16-byte LDS store takes (v[56:59] and v[60:63] alternate; a row reads its predecessor's bp where that
+                // row left it), so no copy per row; the excised stream's two products with bp -- (1-s) bp and 11 bp --
+                // are ONE packed multiply by the pair (1-s, 11), whose source half op_sel picks (a 64-bit operand must be
+                // an even-aligned pair on gfx950).  Same IEEE operations on the same operands as before: 6 issue slots
+                // per row instead of 8 (+ the copy).  The recurrence wave is bound by its instruction count
+                // (header comment), and the whole kernel by the recurrence wave.
+                typedef float q4 __attribute__((ext_vector_type(4)));
+                typedef float c2 __attribute__((ext_vector_type(2)));
+                const c2 coef = {oms, 11.f};
+#define D2_ROW_KUR(PAIR, HALF, BPREG, DST, SP, P, SPN, PN)                                              \
+    "v_pk_mul_f32 v[54:55], " PAIR ", %[cf] op_sel:[" HALF ",0] op_sel_hi:[" HALF ",1]\n\t"          \
+    "v_add_f32 v54, " SP ", v54\n\t"                                                                  \
+    "v_cmp_gt_f32 vcc, " P ", v55\n\t"                                                                \
+    "v_mul_f32 " SPN ", %[sc], " PN "\n\t"                                                            \
+    "s_nop 0\n\t"                                                                                     \
+    "v_cndmask_b32 " DST ", v54, " BPREG ", vcc\n\t"
+#define D2_ROW_RAW(BPREG, DST, SP, SPN, PN)                                                             \
+    "v_mul_f32 v54, %[om], " BPREG "\n\t"                                                             \
+    "v_mul_f32 " SPN ", %[sc], " PN "\n\t"                                                            \
+    "v_add_f32 " DST ", " SP ", v54\n\t"
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    float o[4];
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const int j = 4 * q + jj;
-                        const float pnext = pk[j + 1 < T ? j + 1 : j];
-                        float t2, t1n;
-                        if (!KUR) {
-                            // bp = s p + (1-s) bp (:419); the next row's s*p rides along
-                            asm volatile("v_mul_f32 %1, %4, %0\n\t"
-                                         "v_mul_f32 %2, %3, %6\n\t"
-                                         "v_add_f32 %0, %5, %1"
-                                         : "+v"(bp), "=&v"(t2), "=&v"(t1n)
-                                         : "v"(scale), "v"(oms), "v"(t1), "v"(pnext));
-                        } else {
-                            // t2 = (1-s) bp; lim = 11 bp; bpn = s p + t2; clip = p > lim (:490); bp = clip ? bp : bpn.
-                            // The select needs two wait states after the compare on gfx950: the next row's s*p
-                            // (the only independent work there is) and one s_nop.  28 cycles per row measured;
-                            // a v_cmpx that masks the add instead is slower (36: exec hazards).
-                            float lim;
-                            asm volatile("v_mul_f32 %1, %5, %0\n\t"
-                                         "v_mul_f32 %2, 0x41300000, %0\n\t"
-                                         "v_add_f32 %1, %7, %1\n\t"
-                                         "v_cmp_gt_f32 vcc, %6, %2\n\t"
-                                         "v_mul_f32 %3, %4, %8\n\t"
-                                         "s_nop 0\n\t"
-                                         "v_cndmask_b32 %0, %1, %0, vcc"
-                                         : "+v"(bp), "=&v"(t2), "=&v"(lim), "=&v"(t1n)
-                                         : "v"(scale), "v"(oms), "v"(pk[j]), "v"(t1), "v"(pnext)
-                                         : "vcc");
-                        }
-                        t1 = t1n;
-                        o[jj] = bp;
+                    const float p0 = pk[4 * q], p1 = pk[4 * q + 1], p2 = pk[4 * q + 2], p3 = pk[4 * q + 3];
+                    const float p4 = pk[4 * q + 4 < T ? 4 * q + 4 : 4 * q + 3];
+                    float ta, tb, t1n;
+                    q4 o;
+                    if (!KUR) {
+                        // bp = s p + (1-s) bp (:419); the next row's s*p rides along
+                        if ((q & 1) == 0)
+                            asm volatile(D2_ROW_RAW("v63", "v56", "%[sp0]", "%[ta]", "%[p1]")
+                                         D2_ROW_RAW("v56", "v57", "%[ta]", "%[tb]", "%[p2]")
+                                         D2_ROW_RAW("v57", "v58", "%[tb]", "%[ta]", "%[p3]")
+                                         D2_ROW_RAW("v58", "v59", "%[ta]", "%[tn]", "%[p4]")
+                                         : "={v[56:59]}"(o), [ta] "=&v"(ta), [tb] "=&v"(tb), [tn] "=&v"(t1n)
+                                         : "{v63}"(bp), [sp0] "v"(t1), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [p4] "v"(p4),
+                                           [sc] "v"(scale), [om] "v"(oms)
+                                         : "v54");
+                        else
+                            asm volatile(D2_ROW_RAW("v59", "v60", "%[sp0]", "%[ta]", "%[p1]")
+                                         D2_ROW_RAW("v60", "v61", "%[ta]", "%[tb]", "%[p2]")
+                                         D2_ROW_RAW("v61", "v62", "%[tb]", "%[ta]", "%[p3]")
+                                         D2_ROW_RAW("v62", "v63", "%[ta]", "%[tn]", "%[p4]")
+                                         : "={v[60:63]}"(o), [ta] "=&v"(ta), [tb] "=&v"(tb), [tn] "=&v"(t1n)
+                                         : "{v59}"(bp), [sp0] "v"(t1), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [p4] "v"(p4),
+                                           [sc] "v"(scale), [om] "v"(oms)
+                                         : "v54");
+                    } else {
+                        // t2 = (1-s) bp; lim = 11 bp; bpn = s p + t2; clip = p > lim (:490); bp = clip ? bp : bpn.
+                        // The select needs two wait states after the compare on gfx950: the next row's s*p
+                        // (the only independent work there is) and one s_nop.  A v_cmpx that masks the add instead
+                        // is slower (exec hazards).
+                        if ((q & 1) == 0)
+                            asm volatile(D2_ROW_KUR("v[62:63]", "1", "v63", "v56", "%[sp0]", "%[p0]", "%[ta]", "%[p1]")
+                                         D2_ROW_KUR("v[56:57]", "0", "v56", "v57", "%[ta]", "%[p1]", "%[tb]", "%[p2]")
+                                         D2_ROW_KUR("v[56:57]", "1", "v57", "v58", "%[tb]", "%[p2]", "%[ta]", "%[p3]")
+                                         D2_ROW_KUR("v[58:59]", "0", "v58", "v59", "%[ta]", "%[p3]", "%[tn]", "%[p4]")
+                                         : "={v[56:59]}"(o), [ta] "=&v"(ta), [tb] "=&v"(tb), [tn] "=&v"(t1n)
+                                         : "{v63}"(bp), [sp0] "v"(t1), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3),
+                                           [p4] "v"(p4), [sc] "v"(scale), [cf] "v"(coef)
+                                         : "vcc", "v54", "v55", "v62");
+                        else
+                            asm volatile(D2_ROW_KUR("v[58:59]", "1", "v59", "v60", "%[sp0]", "%[p0]", "%[ta]", "%[p1]")
+                                         D2_ROW_KUR("v[60:61]", "0", "v60", "v61", "%[ta]", "%[p1]", "%[tb]", "%[p2]")
+                                         D2_ROW_KUR("v[60:61]", "1", "v61", "v62", "%[tb]", "%[p2]", "%[ta]", "%[p3]")
+                                         D2_ROW_KUR("v[62:63]", "0", "v62", "v63", "%[ta]", "%[p3]", "%[tn]", "%[p4]")
+                                         : "={v[60:63]}"(o), [ta] "=&v"(ta), [tb] "=&v"(tb), [tn] "=&v"(t1n)
+                                         : "{v59}"(bp), [sp0] "v"(t1), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3),
+                                           [p4] "v"(p4), [sc] "v"(scale), [cf] "v"(coef)
+                                         : "vcc", "v54", "v55", "v58");
                     }
-                    s_u[buf][q][lane] = make_float4(o[0], o[1], o[2], o[3]);
+                    t1 = t1n;
+                    bp = o.w;
+                    *(q4 *)&s_u[buf][q][lane] = o;
                 }
+#undef D2_ROW_KUR
+#undef D2_ROW_RAW
                 cu.next(cps);
             }
             step_barrier();
@@ -633,17 +674,26 @@ hipError_t launch_detect_pow(pb_handle *h, int nseg, bool fine_grained)
         a.ready = h->d_ready;
         for (int i = 0; i < nseg && i < PB_FG_MAXSEG; ++i) a.target[i] = (unsigned)h->chunk_rows * h->ready_epoch[h->cur_set][i];
     }
-    dim3 grid(PB_NCHANOUT / 32, h->cfg.rfi_mode == 2 ? 2 : 1, h->A);
+    // Several antennas in the handle: one launch for all of them (grid z = A: A detect workgroups of ~50 KB on every CU
+    // while it runs, i.e. room for ONE channeliser workgroup of the next batch beside them at A = 2), or one launch per
+    // antenna back to back (PB_DETECT_SERIAL=1): the recurrence is latency-bound, an antenna's 256 workgroups take as
+    // long alone as in company, and one detect workgroup per CU leaves the channeliser two slots instead of one.
+    const bool serial = h->sched.detect_serial && h->A > 1 && !fine_grained;
+    dim3 grid(PB_NCHANOUT / 32, h->cfg.rfi_mode == 2 ? 2 : 1, serial ? 1 : h->A);
+    a.ant0 = 0;
     // three chunks in flight where detect runs wholly beside the next batch's channeliser (it flags its own rows and
     // starts straight behind the previous one), two otherwise (measured both ways, see the comment on DEPTH)
     const int depth_env = h->sched.detect_depth;     // PB_DETECT_DEPTH 2 / 3: timing experiments
     const bool deep = depth_env ? depth_env == 3
                                 : (D2_DEPTH_OVERLAPPED == 3 && pb_fused_kurtosis(h) && h->cfg.taps == 1 && h->sets.size() >= 2 && h->A == 1);
-    if (h->R % 32 == 0) {
-        if (deep) launch_all<32, 3>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
-        else launch_all<32, 2>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
-    } else {
-        launch_all<8, 2>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
+    for (int ai = 0; ai < (serial ? h->A : 1); ++ai) {
+        a.ant0 = ai;
+        if (h->R % 32 == 0) {
+            if (deep) launch_all<32, 3>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
+            else launch_all<32, 2>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
+        } else {
+            launch_all<8, 2>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
+        }
     }
     return hipGetLastError();
 }
