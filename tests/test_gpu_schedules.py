@@ -66,22 +66,25 @@ def _run(lp, monkeypatch, x, mode, taps=1, host=None):
     monkeypatch.setenv("PB_DETECT_DEPTH", str(mode.get("depth", 0)))
     monkeypatch.setenv("PB_COPY_DMA", str(mode.get("copy_dma", 0)))
     nsets = mode["nsets"]
+    A = mode.get("nant", 1)
     raw, kur = [], []
 
     def stage(h):
-        for s in range(S):
-            if mode["feed"] == "host":
-                h.submit_planar(0, s, host[s, 0], host[s, 1])
-            else:
-                base = x.data_ptr() + s * 2 * N
-                h.submit_planar_dev(0, s, base, base + N, N)
+        for a in range(A):                       # (antenna a gets the segments rotated by a: different data)
+            for s in range(S):
+                src = (s + a) % S
+                if mode["feed"] == "host":
+                    h.submit_planar(a, s, host[src, 0], host[src, 1])
+                else:
+                    base = x.data_ptr() + src * 2 * N
+                    h.submit_planar_dev(a, s, base, base + N, N)
 
     def collect(h, b):
         h.select_set(b % nsets)
-        raw.append(h.fetch_view(0, 0, S).copy())
-        kur.append(h.fetch_view(0, 1, S).copy())
+        raw.append(np.concatenate([h.fetch_view(a, 0, S).copy() for a in range(A)]))
+        kur.append(np.concatenate([h.fetch_view(a, 1, S).copy() for a in range(A)]))
 
-    with lp.PbHandle(nant=1, nbit=8, rfi_mode=2, rows_per_seg=R, max_seg=S, nsets=nsets, taps=taps) as h:
+    with lp.PbHandle(nant=A, nbit=8, rfi_mode=2, rows_per_seg=R, max_seg=S, nsets=nsets, taps=taps) as h:
         if mode["feed"] == "resident":
             for st in range(nsets):
                 h.select_set(st)
@@ -96,7 +99,8 @@ def _run(lp, monkeypatch, x, mode, taps=1, host=None):
                 collect(h, b - (nsets - 1))
         for b in range(max(0, NB - (nsets - 1)), NB):
             collect(h, b)
-        bp = h.get_bandpass(0)
+        bps = [h.get_bandpass(a) for a in range(A)]
+        bp = (np.concatenate([b[0] for b in bps]), np.concatenate([b[1] for b in bps]))
     return raw, kur, bp
 
 
@@ -147,6 +151,30 @@ def test_every_scheduling_mode_gives_the_same_bytes_taps4(monkeypatch):
         if base is None:
             base = got
             assert (got[1][0] != got[0][0]).any() and len(set(b.tobytes() for b in got[0])) == NB
+            continue
+        for b in range(NB):
+            assert np.array_equal(got[0][b], base[0][b]), "raw stream, batch %d: %s" % (b, _name(m))
+            assert np.array_equal(got[1][b], base[1][b]), "excised stream, batch %d: %s" % (b, _name(m))
+        for i in range(2):
+            assert np.array_equal(got[2][i].view(np.uint32), base[2][i].view(np.uint32)), "bandpass %d: %s" % (i, _name(m))
+
+
+def test_two_antennas_per_handle_scheduling_modes_agree(monkeypatch):
+    """BASELINE configs[3]'s per-GPU shape (two antennas in one handle, detect's grid z = 2, ring two chunks deep):
+    1 / 2 / 3 buffer sets, detect beside or behind, resident or re-staged input."""
+    lp = libpb()
+    x = _input()
+    host = x.cpu().numpy().reshape(S, 2, N)
+    modes = [dict(nsets=1, fuse=1, feed="staged", overlap=1, kur_early=1, nant=2)]
+    for nsets, ov, feed in itertools.product((2, 3), (1, 0), ("resident", "staged")):
+        modes.append(dict(nsets=nsets, fuse=1, feed=feed, overlap=ov, kur_early=1, nant=2))
+    base = None
+    for m in modes:
+        got = _run(lp, monkeypatch, x, m, host=host)
+        if base is None:
+            base = got
+            half = got[0][0].size // 2
+            assert (got[0][0][:half] != got[0][0][half:]).any()          # the two antennas carry different data
             continue
         for b in range(NB):
             assert np.array_equal(got[0][b], base[0][b]), "raw stream, batch %d: %s" % (b, _name(m))

@@ -88,20 +88,6 @@ __global__ __launch_bounds__(256) void k_copy_out(uint4 *__restrict__ dst, const
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
-// One wave that sleeps for `us` microseconds: holds the stream it is queued on back by that much (PbSched::chan_delay_us)
-__global__ void k_delay(unsigned long long ticks)
-{
-    const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + ticks;      // 100 MHz
-    while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(8);
-}
-
-hipError_t launch_delay(int us, hipStream_t st)
-{
-    if (us <= 0) return hipSuccess;
-    k_delay<<<1, 64, 0, st>>>((unsigned long long)us * 100ull);
-    return hipGetLastError();
-}
-
 hipError_t launch_copy_out(const PbSched &sched, uint8_t *host_pinned, const uint8_t *dev, size_t nbytes, hipStream_t st)
 {
     if (nbytes == 0) return hipSuccess;

@@ -50,7 +50,6 @@ struct Detect2Args {
     int target_stream;
     size_t trim, ave_per_seg;
     int S, R, nseg;
-    int ant0;                // blockIdx.z counts antennas from here (one launch per antenna: PbSched::detect_serial)
     float scale, oms, tscale;
     // Fine-grained coupling to the channeliser of the SAME batch, which is still running (pb_internal.h): chunk (seg,
     // rb) of antenna ant may be read once ready[(ant * S + seg) * cps + rb] has reached target[seg]; nullptr: every
@@ -334,11 +333,13 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
                                              float (*s_u0)[64], float (*s_w)[T])
 {
     // the wave index in a scalar register: every role test is a scalar branch, the step loops run on scalar counters
+    // (Two detect workgroups per CU -- two antennas per handle -- already have their recurrence waves on different
+    //  SIMDs: swapping waves 0 <-> 2 in the odd antennas' workgroups made detect 12 % slower alone, r05_notes.md.)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int cg = blockIdx.x;
     constexpr int stream = KUR ? 1 : 0;
     constexpr int NQ = T / 4, NG = T / PB_NSCRUNCH;
-    const int ant = a.ant0 + (int)blockIdx.z;
+    const int ant = blockIdx.z;
     const int R = a.R, cps = R / T, nchunk = a.nseg * cps;
     const int ntime = R / PB_NSCRUNCH;
     const float *wrow = a.wrow + (size_t)ant * a.S * R;
@@ -674,26 +675,17 @@ hipError_t launch_detect_pow(pb_handle *h, int nseg, bool fine_grained)
         a.ready = h->d_ready;
         for (int i = 0; i < nseg && i < PB_FG_MAXSEG; ++i) a.target[i] = (unsigned)h->chunk_rows * h->ready_epoch[h->cur_set][i];
     }
-    // Several antennas in the handle: one launch for all of them (grid z = A: A detect workgroups of ~50 KB on every CU
-    // while it runs, i.e. room for ONE channeliser workgroup of the next batch beside them at A = 2), or one launch per
-    // antenna back to back (PB_DETECT_SERIAL=1): the recurrence is latency-bound, an antenna's 256 workgroups take as
-    // long alone as in company, and one detect workgroup per CU leaves the channeliser two slots instead of one.
-    const bool serial = h->sched.detect_serial && h->A > 1 && !fine_grained;
-    dim3 grid(PB_NCHANOUT / 32, h->cfg.rfi_mode == 2 ? 2 : 1, serial ? 1 : h->A);
-    a.ant0 = 0;
+    dim3 grid(PB_NCHANOUT / 32, h->cfg.rfi_mode == 2 ? 2 : 1, h->A);
     // three chunks in flight where detect runs wholly beside the next batch's channeliser (it flags its own rows and
     // starts straight behind the previous one), two otherwise (measured both ways, see the comment on DEPTH)
     const int depth_env = h->sched.detect_depth;     // PB_DETECT_DEPTH 2 / 3: timing experiments
     const bool deep = depth_env ? depth_env == 3
                                 : (D2_DEPTH_OVERLAPPED == 3 && pb_fused_kurtosis(h) && h->cfg.taps == 1 && h->sets.size() >= 2 && h->A == 1);
-    for (int ai = 0; ai < (serial ? h->A : 1); ++ai) {
-        a.ant0 = ai;
-        if (h->R % 32 == 0) {
-            if (deep) launch_all<32, 3>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
-            else launch_all<32, 2>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
-        } else {
-            launch_all<8, 2>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
-        }
+    if (h->R % 32 == 0) {
+        if (deep) launch_all<32, 3>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
+        else launch_all<32, 2>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
+    } else {
+        launch_all<8, 2>(a, h->cfg.rfi_mode, h->cfg.npol, h->cfg.nbit, grid, h->stream);
     }
     return hipGetLastError();
 }

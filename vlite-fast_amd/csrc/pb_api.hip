@@ -71,8 +71,6 @@ PbSched pb_read_sched()
     s.copy_wgs = env_int("PB_COPY_WGS", 8);
     s.det_cus = env_int("PB_DET_CUS", 0);
     s.det_prio = env_int("PB_DET_PRIO", 1);
-    s.detect_serial = env_int("PB_DETECT_SERIAL", 0);
-    s.chan_delay_us = env_int("PB_CHAN_DELAY_US", 0);
     return s;
 }
 
@@ -1056,7 +1054,6 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         }
     } else {
         StageTimer t(h, PB_ST_CHANNELIZE);
-        if (h->sched.chan_delay_us > 0 && h->sets.size() >= 2 && h->last_set >= 0) HIPCHK(h, launch_delay(h->sched.chan_delay_us, h->stream));
         if (!(pb_skip_mask() & 1))
             HIPCHK(h, h->cfg.taps == 4 ? launch_channelize_pfb(h, nseg, inject_now) : launch_channelize(h, nseg, inject_now));
         t.stop();

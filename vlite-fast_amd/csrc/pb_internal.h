@@ -54,9 +54,6 @@ struct PbSched {
     int copy_wgs;         // PB_COPY_WGS (8): workgroups of the copy-out kernel
     int det_cus;          // PB_DET_CUS (0): CU mask of the detect stream (timing experiments)
     int det_prio;         // PB_DET_PRIO (1): detect's stream at the highest priority
-    int chan_delay_us;    // PB_CHAN_DELAY_US (0): the channeliser starts this long after the previous one has ended, so that
-                          // the previous batch's detect -- released by the same event -- places its workgroups first
-    int detect_serial;    // PB_DETECT_SERIAL: several antennas per handle: one detect launch per antenna, back to back
 };
 PbSched pb_read_sched();
 
@@ -183,7 +180,6 @@ hipError_t launch_inject_c64(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_detect(pb_handle *h, int nseg, int inject_now, bool fine_grained = false);
 hipError_t launch_detect_pow(pb_handle *h, int nseg, bool fine_grained = false);
 // device -> pinned host copy done by a kernel (see k_detect.hip: hipMemcpyAsync blocks the host now and then)
-hipError_t launch_delay(int us, hipStream_t st);
 hipError_t launch_copy_out(const PbSched &sched, uint8_t *host_pinned, const uint8_t *dev, size_t nbytes, hipStream_t st);
 hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now);
