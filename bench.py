@@ -424,6 +424,8 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
         cmod = importlib.import_module("vlite-fast_amd.coadd")
         leg = cmod.IncoherentCoadd(h, nant_total, dev, root=0, backend=args.dist_backend, order=args.coadd_order,
                                    parts=int(os.environ.get("PB_COADD_PARTS", "7")))     # (parts: timing experiments)
+        if world == 1 and getattr(args, "emulate_world", 0) > 1:
+            leg.emulate_root_of(args.emulate_world, dev)
     nstream_out = (0, 1) if args.rfi_mode == 2 else ((0,) if args.rfi_mode == 0 else (1,))
     state = {"k": 0, "sink": 0, "coadds": 0}
 
@@ -665,6 +667,9 @@ def build_parser():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power", action="store_true", help="skip the 2-s power / clock / throttle sample (roofline.power)")
     ap.add_argument("--no-extras", action="store_true", help="skip the taps4 / ingest / search / configs3 sub-records")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="with --coadd-selftest: also run the ROOT's tree over this many gathered planes per step (timing of "
+                         "rank 0's extra device work in a world of that size; no collective, coadded bytes invalid)")
     ap.add_argument("--coadd-selftest", action="store_true",
                     help="N = 1 only: print the step with the incoherent-sum leg of the N > 1 path switched on "
                          "(fp32 planes kept, local sum, RCCL reduce in a one-rank group, requantisation) instead of the bench line")
@@ -772,6 +777,7 @@ def main():
         withc = run_chain(torch, dist, lp, args, dev, local, 0, 1, args.taps, args.steps, args.warmup, coadd=True)
         print(json.dumps({"coadd_selftest": {"ms_per_step_plain": round(plain["ms_per_step"], 4),
                                              "ms_per_step_with_coadd_leg": round(withc["ms_per_step"], 4),
+                                             "emulated_world": args.emulate_world or 1, "antennas_per_gpu": A,
                                              "stage_ms_per_step": withc["stage_ms_per_step"]}}))
         dist.destroy_process_group()
         return

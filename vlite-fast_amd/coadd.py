@@ -139,6 +139,9 @@ class IncoherentCoadd(object):
         self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         handle.sync()
         handle.set_coadd_stream(self.stream.cuda_stream if self.stream is not None else 0)
+        # bench.py --coadd-selftest --emulate-world W (one GPU): the ROOT's device work of a W-rank world -- the tree over
+        # W gathered planes (stand-ins: copies of nothing in particular; results invalid) -- without the collective
+        self.emulate = None
         self.queued = 0
         self.timing = False                # bench.py: device time of the collective (event pairs on the leg's stream)
         self._pairs = []
@@ -207,6 +210,9 @@ class IncoherentCoadd(object):
                         h.coadd_local_tree(nseg, [j], ds.data_ptr() + 4 * self.n * j)
             if self.parts & 2 and self.world > 1:
                 self._collective(ds)
+            if self.emulate is not None:
+                h.coadd_tree(self.emulate[1], self.emulate[2].data_ptr(), nfl)
+                final = self.emulate[2]
             if self.rank == self.root and self.parts & 4:
                 if self.order == "tree" and self.world > 1:
                     h.coadd_tree(self.leaves, self.total.data_ptr(), nfl)
@@ -215,6 +221,12 @@ class IncoherentCoadd(object):
             if self.use_target:
                 h.coadd_release()
         self.queued += 1
+
+    def emulate_root_of(self, W, device):
+        """timing only: queue() also runs the root's tree over W planes of this size (see __init__)"""
+        g = torch.zeros(W * self.n, dtype=torch.float32, device=device)
+        tot = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.emulate = (g, [g.data_ptr() + 4 * self.n * r for r in tree_order(range(W))], tot)
 
     def coadded(self, nseg, age=0):
         if self.rank != self.root:
