@@ -423,7 +423,7 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
         # reduced straight into the leg's buffer of the batch's set and the local sum needs no kernel.
         cmod = importlib.import_module("vlite-fast_amd.coadd")
         leg = cmod.IncoherentCoadd(h, nant_total, dev, root=0, backend=args.dist_backend, order=args.coadd_order,
-                                   parts=int(os.environ.get("PB_COADD_PARTS", "7")))     # (parts: timing experiments)
+                                   layout=args.coadd_layout, parts=int(os.environ.get("PB_COADD_PARTS", "7")))     # (parts: timing experiments)
         if world == 1 and getattr(args, "emulate_world", 0) > 1:
             leg.emulate_root_of(args.emulate_world, dev)
     nstream_out = (0, 1) if args.rfi_mode == 2 else ((0,) if args.rfi_mode == 0 else (1,))
@@ -564,9 +564,12 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
             med = per_rank[int(np.argsort(dts)[len(dts) // 2])]
             res["per_rank"] = {"ms_per_step_min": round(min(med) / steps * 1e3, 4), "ms_per_step_max": round(max(med) / steps * 1e3, 4),
                                "ms_per_step": [round(x / steps * 1e3, 4) for x in med]}
+            res["coadd_layout"] = leg.layout if leg is not None else None
             res["reduce_leg"] = {"device_ms_per_call_root": round(red_ms / red_n, 4) if red_n else None, "calls": red_n,
                                  "bytes_per_call": int(S * h.ave_per_seg * 4),
-                                 "note": "event pair around dist.reduce on the leg's stream, beside the next batch's kernels"}
+                                 "note": "event pair around the leg's collective(s) on its stream (sliced: all-to-all of plane "
+                                         "slices + gather of code bytes, with this rank's tree and requantisation between "
+                                         "them; root: gather of planes; fast: reduce), beside the next batch's kernels"}
         step_bytes = sum(alg[k] for k in stages) * S * A
         res["roofline"]["pipeline"] = {"algorithmic_bytes_per_step": step_bytes,
                                        "achieved": round(step_bytes / (dt / steps) / 1e9, 1),
@@ -660,6 +663,9 @@ def build_parser():
     ap.add_argument("--coadd-order", choices=["tree", "fast"], default="tree",
                     help="N > 1: tree (default) = the defined order of the fp32 additions (local tree, gather to rank 0, "
                          "root tree: the same coadded bytes on any number of GPUs); fast = one RCCL reduce(SUM)")
+    ap.add_argument("--coadd-layout", choices=["auto", "root", "sliced"], default="auto",
+                    help="N > 1, tree order: sliced (auto) = all-to-all of plane slices, every rank sums and requantises 1/N "
+                         "of the plane, code bytes gathered to rank 0; root = every plane gathered to rank 0")
     ap.add_argument("--share-gpus", action="store_true",
                     help="rehearsal only: let more ranks than there are GPUs run (ranks wrap onto the cards); "
                          "without it a run with fewer GPUs than ranks fails")
@@ -819,7 +825,7 @@ def main():
             out["gpus_visible"] = ndev
             out["per_rank"] = r.get("per_rank")
             out["reduce_leg"] = r.get("reduce_leg")
-            out["coadd_order"] = {"order": args.coadd_order,
+            out["coadd_order"] = {"order": args.coadd_order, "layout": r.get("coadd_layout"),
                                   "meaning": ("antennas split by index parity, recursively (DESIGN.md section 6): every rank's "
                                               "node by pb_coadd_local_tree, one fp32 plane per rank gathered to rank 0, "
                                               "pb_coadd_tree there; bytes independent of the number of GPUs")

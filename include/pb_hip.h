@@ -217,6 +217,17 @@ int pb_coadd_local_codes(pb_handle *h, int nseg, float *d_sum, int accumulate);
 #define PB_COADD_MAX_LEAVES 32
 int pb_coadd_local_tree(pb_handle *h, int nseg, const int32_t *ant_order, int n, float *d_dst);
 int pb_coadd_tree(pb_handle *h, const float *const *d_leaves, int n, float *d_dst, size_t nfloat);
+/* The root's work spread over the ranks ("sliced" layout of the ordered sum, coadd.py): every rank sums and
+ * requantises 1/W of the plane, and only code bytes travel to rank 0.
+ *   pb_coadd_digitise: d_codes[0 .. nfloat * nbit / 8) = sel_and_dig(d_sum[0 .. nfloat) / sqrt(nant_total)) for a FLAT
+ *     range of the npol = 1 plane (sample i of the plane is sample i of the code stream; with two polarisations the code
+ *     stream interleaves them, src/pb_kernels.cu:723-727, and a flat range is not a code range: PB_ESTATE).  Device to
+ *     device, on the coadd stream; nfloat a multiple of 8.
+ *   pb_coadd_publish: the coadded code bytes of one batch, assembled on the device by the caller (the gathered
+ *     slices), go to the pinned host buffer that pb_coadd_fetch_ptr hands out -- what pb_coadd_finish does with the
+ *     bytes it computes itself.  nbytes <= max_seg * code_bytes_per_seg. */
+int pb_coadd_digitise(pb_handle *h, const float *d_sum, size_t nfloat, int nant_total, uint8_t *d_codes);
+int pb_coadd_publish(pb_handle *h, const uint8_t *d_codes, size_t nbytes);
 int pb_set_coadd_target(pb_handle *h, float *d_sum);
 int pb_coadd_release(pb_handle *h);
 /* Run pb_coadd_local / pb_coadd_finish (and so the collective the host queues between them) on

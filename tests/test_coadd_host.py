@@ -47,7 +47,7 @@ class FakeCoaddHandle(object):
 
     def __init__(self, nant, nsets=2):
         self.nant, self.nsets, self.trim, self.max_seg, self.ave_per_seg = nant, nsets, TRIM, SEG, TRIM
-        self.cfg = argparse.Namespace(fft_backend=1)
+        self.cfg = argparse.Namespace(fft_backend=1, npol=1, nbit=8)
         self.cur_set = 0
         self.staged = [[None] * nant for _ in range(nsets)]
         self.done = [[None] * nant for _ in range(nsets)]
@@ -110,6 +110,18 @@ class FakeCoaddHandle(object):
         self.co[slot] = (v.view(np.uint32) & np.uint32(0xFF)).astype(np.uint8)
         self.co_last = slot
 
+    def coadd_digitise(self, ptr, nfloat, nant_total, codes_ptr):
+        v = self._mem(ptr, nfloat) * np.float32(1.0 / np.sqrt(float(nant_total)))
+        out = np.ctypeslib.as_array((C.c_uint8 * nfloat).from_address(codes_ptr))
+        out[:] = (v.view(np.uint32) & np.uint32(0xFF)).astype(np.uint8)
+        self.calls.append(("coadd_digitise", nfloat))
+
+    def coadd_publish(self, codes_ptr, nbytes):
+        slot = self.co_last ^ 1
+        self.co[slot] = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(codes_ptr)).copy()
+        self.co_last = slot
+        self.calls.append(("coadd_publish", nbytes))
+
     def coadd_view(self, nseg, age=0):
         return self.co[self.co_last if age == 0 else self.co_last ^ 1]
 
@@ -140,7 +152,7 @@ def _stream(ant):
     return hdr, body
 
 
-def _worker(rank, world, port, tmp, NANT, order):
+def _worker(rank, world, port, tmp, NANT, order, layout="auto"):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -149,7 +161,7 @@ def _worker(rank, world, port, tmp, NANT, order):
     vdif, sigproc, dada, coadd, host = _mods()
     args = host.build_parser().parse_args(["--replay"] + ["unused"] * NANT + ["-b", "8", "-r", "2", "-w", "2", "--datadir", tmp,
                                            "--logdir", os.path.join(tmp, "logs"), "--rows-per-seg", str(R),
-                                           "--dist-backend", "gloo", "--coadd-order", order,
+                                           "--dist-backend", "gloo", "--coadd-order", order, "--coadd-layout", layout,
                                            "--out-sink", os.path.join(tmp, "co_ring.bin")])
     mine = coadd.antennas_of_rank(NANT, rank, world)
     rings = {}
@@ -161,22 +173,22 @@ def _worker(rank, world, port, tmp, NANT, order):
         r.end_of_data()
         rings[a] = r
     h = FakeCoaddHandle(len(mine), nsets=2)
-    co = coadd.IncoherentCoadd(h, NANT, torch.device("cpu"), root=0, backend="gloo", order=order)
+    co = coadd.IncoherentCoadd(h, NANT, torch.device("cpu"), root=0, backend="gloo", order=order, layout=layout)
     rc = host.run(args, rank=rank, world=world, local=0, rings=rings, handle=h, dist=dist, device=torch.device("cpu"), coadd=co)
     with open(os.path.join(tmp, "rc%d" % rank), "w") as f:
-        f.write("%d %s" % (rc, [c for c in h.calls if c[0] in ("submit", "coadd_tree")]))
+        f.write("%d %s" % (rc, [c for c in h.calls if c[0] in ("submit", "coadd_tree", "coadd_digitise", "coadd_publish")] + [("layout", co.layout)]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run_world(tmp_path, world, NANT, order):
+def _run_world(tmp_path, world, NANT, order, layout="auto"):
     os.environ["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"),
                                                 os.environ.get("PYTHONPATH", "")])
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     ctx = mp.get_context("spawn")
     port = 29900 + (os.getpid() * 7 + world * 13 + NANT) % 2000
     tmp = str(tmp_path)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, tmp, NANT, order)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tmp, NANT, order, layout)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -201,11 +213,14 @@ def _quantise(tot, NANT):
     return (v.view(np.uint32) & np.uint32(0xFF)).astype(np.uint8).tobytes()
 
 
-@pytest.mark.parametrize("world,NANT", [(8, 16), (3, 7), (5, 11), (4, 6)])
-def test_coadd_host_tree_order_files_and_sum(tmp_path, world, NANT):
-    """(8, 16): two antennas per rank, configs[3]; (3, 7) and (5, 16): worlds that are not powers of two ship every
+@pytest.mark.parametrize("world,NANT,layout", [(8, 16, "auto"), (8, 16, "root"), (3, 7, "auto"), (5, 11, "auto"), (4, 6, "sliced"),
+                                               (2, 4, "root")])
+def test_coadd_host_tree_order_files_and_sum(tmp_path, world, NANT, layout):
+    """(8, 16): two antennas per rank, configs[3] -- with the root's work spread over the ranks ("auto" -> "sliced":
+    all-to-all of plane slices, every rank sums and requantises an eighth, code bytes gathered) and with every plane
+    gathered to rank 0 ("root"): the SAME bytes; (3, 7) and (5, 11): worlds that are not powers of two ship every
     antenna's plane, shards 3/2/2 and 3/2/2/2/2; (4, 6): a power of two with uneven shards 2/2/1/1"""
-    _run_world(tmp_path, world, NANT, "tree")
+    _run_world(tmp_path, world, NANT, "tree", layout)
     vdif, sigproc, dada, coadd, host = _mods()
     # the sum covers seconds 3600 and 3601: antenna 1's early second is skipped, antenna 2's stream ends with 3602,
     # which -- being its last -- is dropped
@@ -229,6 +244,16 @@ def test_coadd_host_tree_order_files_and_sum(tmp_path, world, NANT):
     n0 = len(coadd.antennas_of_rank(NANT, 0, world))
     assert [(c[2], c[3]) for c in calls0 if c[0] == "submit"] == [(i, s) for s in secs for i in range(n0)]
     assert [c[1] for c in calls0 if c[0] == "coadd_tree"] == [world if coadd.is_pow2(world) else NANT] * len(secs)
+    sliced = coadd.is_pow2(world) and layout != "root"
+    assert ("layout", "sliced" if sliced else "root") in calls0
+    nfl = SEG * TRIM
+    assert [c[1] for c in calls0 if c[0] == "coadd_digitise"] == ([nfl // world] * len(secs) if sliced else [])
+    assert [c[1] for c in calls0 if c[0] == "coadd_publish"] == ([nfl] * len(secs) if sliced else [])
+    if sliced:          # every rank did its share: the tree over `world` slices and its slice's requantisation
+        calls1 = eval((tmp_path / ("rc%d" % (world - 1))).read_text().split(" ", 1)[1])
+        assert [c[1] for c in calls1 if c[0] == "coadd_tree"] == [world] * len(secs)
+        assert [c[1] for c in calls1 if c[0] == "coadd_digitise"] == [nfl // world] * len(secs)
+        assert not [c for c in calls1 if c[0] == "coadd_publish"]
     # the order really matters for these data (else the test could not tell a wrong plan from a right one)
     naive = np.float32(0)
     for pl in planes:
@@ -340,6 +365,9 @@ def test_incoherent_coadd_source_switch():
         coadd.IncoherentCoadd(H(1), 1, "cpu", source="sum")
     with pytest.raises(ValueError):
         coadd.IncoherentCoadd(H(1), 1, "cpu", order="ring")
+    with pytest.raises(ValueError):
+        coadd.IncoherentCoadd(H(1), 1, "cpu", layout="sliced")          # a world of one has nothing to slice
+    assert coadd.IncoherentCoadd(H(1), 1, "cpu", backend="gloo").layout == "root"
     hf = H(2)
     hf.done[0] = [rng.integers(0, 256, (2, SEG * TRIM), dtype=np.uint8) for _ in range(2)]
     cf = coadd.IncoherentCoadd(hf, 2, "cpu", backend="gloo", order="fast")

@@ -42,13 +42,16 @@ def _dump(path, data, station):
             f.write(vdif.frame_block(p0, p1, 3600 + s, 33, station).tobytes())
 
 
-@pytest.mark.parametrize("nbit,NANT,ranks,order", [(8, 8, 4, "tree"), (8, 4, 2, "tree"), (2, 3, 2, "tree"), (8, 5, 3, "tree"),
-                                                   (8, 4, 2, "fast")])
-def test_ranks_antennas_coadded_fil_is_byte_exact(tmp_path, oracle, nbit, NANT, ranks, order):
+@pytest.mark.parametrize("nbit,NANT,ranks,order,layout", [(8, 8, 4, "tree", "auto"), (8, 8, 4, "tree", "root"), (8, 4, 2, "tree", "auto"),
+                                                          (2, 3, 2, "tree", "auto"), (4, 4, 2, "tree", "sliced"), (8, 5, 3, "tree", "auto"),
+                                                          (8, 4, 2, "fast", "auto")])
+def test_ranks_antennas_coadded_fil_is_byte_exact(tmp_path, oracle, nbit, NANT, ranks, order, layout):
     """(4 ranks x 8 antennas: two per rank, configs[3]'s shape at half size; 2 ranks x 4: scale exactly 1/2; 2 bit,
     3 antennas: ranks hold {0, 2} and {1}, scale float(1 / sqrt 3); 3 ranks x 5 antennas: not a power of two, every
     antenna's plane goes to the root; "fast": one dist.reduce of left-to-right local sums, whose two-rank association
-    is known)"""
+    is known.  layout: with a power-of-two world and one output polarisation the root's work is spread over the ranks
+    ("auto" -> "sliced": all-to-all of plane slices, every rank sums and requantises its share, code bytes gathered);
+    "root" gathers every plane to rank 0.  The same bytes either way, at 8, 4 and 2 bits.)"""
     nsec = 3 if NANT > 4 else 4                      # -> 2 / 3 s out (the last second of every stream is dropped)
     data = [make_input(80 + a, R, nsec * SEG, rfi=a != 1, dropped=a == 2) for a in range(NANT)]
     dumps = []
@@ -58,7 +61,7 @@ def test_ranks_antennas_coadded_fil_is_byte_exact(tmp_path, oracle, nbit, NANT, 
         dumps.append(p)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
     cmd = [sys.executable, os.path.join(ROOT, "vlite-fast_amd", "coadd_host.py"), "--ranks", str(ranks), "--dist-backend", "gloo",
-           "--share-gpus", "--coadd-order", order, "--replay"] + dumps + ["-b", str(nbit), "-r", "2", "-w", "2", "--datadir", str(tmp_path),
+           "--share-gpus", "--coadd-order", order, "--coadd-layout", layout, "--replay"] + dumps + ["-b", str(nbit), "-r", "2", "-w", "2", "--datadir", str(tmp_path),
            "--logdir", str(tmp_path / "logs"), "--rows-per-seg", str(R), "--out-sink", str(tmp_path / "co_ring.bin")]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
@@ -100,6 +103,8 @@ def test_ranks_antennas_coadded_fil_is_byte_exact(tmp_path, oracle, nbit, NANT, 
     assert want != b"".join(oracle.sel_and_dig(planes[0][s], R, nbit=nbit).tobytes() for s in range(nseg))
     log = "".join(open(os.path.join(str(tmp_path / "logs"), f)).read() for f in os.listdir(str(tmp_path / "logs")))
     assert 'order "%s"' % order in log
+    want_layout = "sliced" if (order == "tree" and ranks in (2, 4) and layout != "root") else "root"
+    assert 'layout "%s"' % want_layout in log
 
 
 def test_single_rank_coadd_of_two_antennas_equals_two_rank_sum(tmp_path, oracle):

@@ -9,7 +9,7 @@ import importlib
 import numpy as np
 import pytest
 
-from helpers import count_tree, libpb, make_input, parity_sum
+from helpers import count_tree, libpb, make_input, parity_sum  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -107,6 +107,50 @@ def test_coadd_local_tree_over_a_handles_antennas(A):
             h.coadd_local_tree(S, [A], dst.data_ptr())
         with pytest.raises((ValueError, lp.PbError)):
             h.coadd_local_tree(S + 1, [0], dst.data_ptr())
+
+
+@pytest.mark.parametrize("nbit", [8, 4, 2])
+def test_coadd_digitise_flat_range_and_publish(oracle, nbit):
+    """pb_coadd_digitise on a flat slice of an npol = 1 plane = the oracle's sel_and_dig of the same samples (the slice a
+    rank requantises in the sliced layout), at 8 / 4 / 2 bits, for slices that start and end inside segments; and
+    pb_coadd_publish hands the assembled bytes out through pb_coadd_fetch_ptr.  npol = 2: refused."""
+    import torch
+    lp = libpb()
+    dev = torch.device("cuda", 0)
+    R, S = 16, 3
+    rng = np.random.default_rng(9)
+    with lp.PbHandle(device=0, nant=1, nbit=nbit, npol=1, rows_per_seg=R, max_seg=S, keep_ave=True) as h:
+        n = S * h.ave_per_seg
+        plane = (rng.standard_normal(n) * 3).astype(np.float32)
+        plane[::501] = np.float32(100.0)
+        plane[7::733] = np.float32(-100.0)
+        nant = 5
+        scale = np.float32(1.0 / np.sqrt(float(nant)))
+        # the oracle quantises a full [ntime][6251] plane: put every segment's 4096 channels where it expects them
+        want = b""
+        for s_ in range(S):
+            full = np.zeros((R // 8, oracle.NCHAN), np.float32)
+            full[:, oracle.CHANMIN:oracle.CHANMIN + 4096] = (plane[s_ * h.ave_per_seg:(s_ + 1) * h.ave_per_seg] * scale).reshape(R // 8, 4096)
+            want += oracle.sel_and_dig(full, R, npol=1, nbit=nbit).tobytes()
+        want = np.frombuffer(want, np.uint8)
+        d = torch.from_numpy(plane).to(dev)
+        codes = torch.zeros(n * nbit // 8, dtype=torch.uint8, device=dev)
+        W = 4
+        sl = n // W
+        for r in range(W):                      # four slices, as four ranks would requantise them
+            h.coadd_digitise(d.data_ptr() + 4 * sl * r, sl, nant, codes.data_ptr() + sl * nbit // 8 * r)
+        h.sync()
+        torch.cuda.synchronize()
+        assert np.array_equal(codes.cpu().numpy(), want)
+        h.coadd_publish(codes.data_ptr(), codes.numel())
+        assert np.array_equal(np.array(h.coadd_view(S, age=0), copy=True), want)
+        with pytest.raises((ValueError, lp.PbError)):
+            h.coadd_digitise(d.data_ptr(), 12, nant, codes.data_ptr())
+        with pytest.raises((ValueError, lp.PbError)):
+            h.coadd_publish(codes.data_ptr(), codes.numel() + 1)
+    with lp.PbHandle(device=0, nant=1, nbit=8, npol=2, rows_per_seg=R, max_seg=1, keep_ave=True) as h2:
+        with pytest.raises((ValueError, lp.PbError)):
+            h2.coadd_digitise(d.data_ptr(), 4096, 1, codes.data_ptr())
 
 
 def test_incoherent_coadd_leg_world1_rccl_gather_path():

@@ -18,6 +18,14 @@ With world a power of two, rank r's antennas {r, r+W, ...} ARE the node S(r, W):
 20 MiB per second of data at 8 GPUs -- far below one link's bandwidth), and the root evaluates the top log2 W levels
 over the partial sums in bit-reversed rank order (pb_coadd_tree).  Any other world size ships the antennas' planes
 themselves and the root evaluates the whole tree: same bytes, more traffic.
+Layout of the tree order across a power-of-two world (layout="auto" picks "sliced" with one output polarisation):
+  "root"    every rank's plane is gathered to rank 0, which evaluates the top levels and requantises: 7 x 20 MiB per
+            second of data into ONE GPU, and rank 0 does ~10 % more device work than the others (profiles/r05_notes.md);
+  "sliced"  every rank evaluates the top levels for 1/W of the plane: ONE all-to-all of plane slices (every xGMI link of
+            the full mesh carries 1/W of a plane, all links at once), pb_coadd_tree over the W received slices -- the same
+            tree per element, hence the same bytes --, the slice requantised where it was summed (pb_coadd_digitise),
+            and only code bytes gathered to rank 0 (7 x 0.65 MiB at 8 bits), which hands them out (pb_coadd_publish).
+            The ranks' loads are equal.
 order="fast" is one RCCL reduce(SUM, fp32) of the locally pre-summed planes to the root: the association is then the
 collective's (ring / tree by topology and message size) and the bytes are not reproducible across world sizes; kept
 for comparison (`--coadd-order fast`).
@@ -83,11 +91,13 @@ class IncoherentCoadd(object):
     """
 
     def __init__(self, handle, nant_total, device, root=0, backend="nccl", group=None, use_target=None, parts=7,
-                 source="planes", order="tree"):
+                 source="planes", order="tree", layout="auto"):
         if source not in ("planes", "codes"):
             raise ValueError("source must be 'planes' or 'codes'")
         if order not in ("tree", "fast"):
             raise ValueError("order must be 'tree' or 'fast'")
+        if layout not in ("auto", "root", "sliced"):
+            raise ValueError("layout must be 'auto', 'root' or 'sliced'")
         self.source = source               # "codes": sum the antennas' quantised bytes (pb_coadd_local_codes)
         if source == "codes":
             use_target = False
@@ -126,8 +136,21 @@ class IncoherentCoadd(object):
                 handle.select_set(st)
                 handle.set_coadd_target(self.sums[st].data_ptr())
             handle.select_set(0)
+        # "sliced": a power-of-two world of more than one rank, the tree order, one output polarisation (a flat range
+        # of the plane is then a range of the code stream)
+        can_slice = order == "tree" and W > 1 and is_pow2(W) and int(getattr(handle.cfg, "npol", 1)) == 1
+        if layout == "sliced" and not can_slice:
+            raise ValueError("the sliced layout needs the tree order, a power-of-two world > 1 and npol = 1")
+        self.layout = "sliced" if (can_slice and layout != "root") else "root"
         self.gath = self.total = self.leaves = None
-        if order == "tree" and W > 1 and self.rank == root:
+        if self.layout == "sliced":
+            nbit = int(handle.cfg.nbit)
+            self.recv = torch.zeros(n, dtype=torch.float32, device=device)            # W slices of n / W floats
+            self.slice_sum = torch.zeros(n // W, dtype=torch.float32, device=device)
+            self.slice_codes = torch.zeros(n // W * nbit // 8, dtype=torch.uint8, device=device)
+            self.all_codes = (torch.zeros(n * nbit // 8, dtype=torch.uint8, device=device) if self.rank == root else None)
+            self.nbit = nbit
+        elif order == "tree" and W > 1 and self.rank == root:
             self.gath = torch.zeros(W * self.ship * n, dtype=torch.float32, device=device)
             self.total = torch.zeros(n, dtype=torch.float32, device=device)
             g0 = self.gath.data_ptr()
@@ -192,6 +215,48 @@ class IncoherentCoadd(object):
                 for r, piece in enumerate(into):
                     self.gath[r * t.numel():(r + 1) * t.numel()].copy_(piece)
 
+    def _sliced(self, ds, nseg, nfl):
+        """the ranks share the root's work: all-to-all of plane slices, the tree over the W slices received, the slice
+        requantised here, code bytes gathered to the root (module docstring).  Runs on the leg's stream."""
+        h, W = self.h, self.world
+        sl = nfl // W                                   # floats per slice (nfl = nseg * ave_per_seg: a multiple of 4096)
+        nb = sl * self.nbit // 8
+        send, recv = ds[:nfl], self.recv[:nfl]
+        timing = self.timing and self.backend == "nccl"
+        if timing:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(self.stream)
+        if self.backend == "nccl":
+            dist.all_to_all_single(recv, send, group=self.group)                 # RCCL: every link of the mesh at once
+        else:                                                                    # rehearsal (gloo): through host memory
+            if self.stream is not None:
+                self.stream.synchronize()
+            t = send.cpu()
+            r = torch.empty_like(t)
+            dist.all_to_all_single(r, t, group=self.group)
+            recv.copy_(r)
+        g0 = recv.data_ptr()
+        h.coadd_tree([g0 + 4 * sl * r for r in tree_order(range(W))], self.slice_sum.data_ptr(), sl)
+        h.coadd_digitise(self.slice_sum.data_ptr(), sl, self.nant_total, self.slice_codes.data_ptr())
+        mine = self.slice_codes[:nb]
+        if self.backend == "nccl":
+            into = list(self.all_codes[:W * nb].split(nb)) if self.rank == self.root else None
+            dist.gather(mine, into, dst=self.root, group=self.group)
+        else:
+            if self.stream is not None:
+                self.stream.synchronize()
+            t = mine.cpu()
+            into = [torch.empty_like(t) for _ in range(W)] if self.rank == self.root else None
+            dist.gather(t, into, dst=self.root, group=self.group)
+            if into is not None:
+                for r, piece in enumerate(into):
+                    self.all_codes[r * nb:(r + 1) * nb].copy_(piece)
+        if timing:
+            ev[1].record(self.stream)
+            self._pairs.append(ev)
+        if self.rank == self.root:
+            h.coadd_publish(self.all_codes.data_ptr(), W * nb)
+
     def queue(self, set_index, nseg):
         h, ds = self.h, self.buffer(set_index)
         h.select_set(set_index)
@@ -208,6 +273,12 @@ class IncoherentCoadd(object):
                 else:
                     for j in range(h.nant):
                         h.coadd_local_tree(nseg, [j], ds.data_ptr() + 4 * self.n * j)
+            if self.layout == "sliced":
+                self._sliced(ds, nseg, nfl)
+                if self.use_target:
+                    h.coadd_release()
+                self.queued += 1
+                return
             if self.parts & 2 and self.world > 1:
                 self._collective(ds)
             if self.emulate is not None:

@@ -75,6 +75,9 @@ def build_parser():
     p.add_argument("--coadd-order", choices=["tree", "fast"], default="tree",
                    help="tree (default): the defined order of the fp32 additions, the same bytes on any number of ranks; "
                         "fast: one reduce(SUM), order left to the collective")
+    p.add_argument("--coadd-layout", choices=["auto", "root", "sliced"], default="auto",
+                   help="tree order over a power-of-two world: sliced (auto, with -P 1) = every rank sums and requantises "
+                        "1/W of the plane, code bytes gathered; root = every plane gathered to rank 0.  The same bytes.")
     p.add_argument("--share-gpus", action="store_true", help="rehearsal only: ranks may wrap onto the cards")
     return p
 
@@ -156,9 +159,9 @@ def run(args, rank=0, world=1, local=0, rings=None, handle=None, dist=None, devi
                              max_seg=SEG_PER_SEC, keep_ave=True, nsets=args.nsets)
     if coadd is None:
         coadd = cmod.IncoherentCoadd(handle, nant, device, root=0, backend=args.dist_backend, source=args.coadd_input,
-                                     order=args.coadd_order)
-    log("INFO", "Incoherent sum: %s of %d antennas over %d rank(s), order \"%s\"."
-        % (args.coadd_input, nant, world, getattr(coadd, "order", args.coadd_order)))
+                                     order=args.coadd_order, layout=args.coadd_layout)
+    log("INFO", "Incoherent sum: %s of %d antennas over %d rank(s), order \"%s\", layout \"%s\"."
+        % (args.coadd_input, nant, world, getattr(coadd, "order", args.coadd_order), getattr(coadd, "layout", "root")))
     ctl = Control(dist, args.dist_backend)
     trim, nsets = handle.trim, handle.nsets
     root = rank == 0

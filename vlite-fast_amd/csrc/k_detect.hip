@@ -207,6 +207,19 @@ __global__ __launch_bounds__(256) void k_coadd_digitise8(const float4 *__restric
     }
 }
 
+// a flat range of the npol = 1 plane: sample i of the plane is sample i of the code stream
+hipError_t launch_coadd_digitise_flat(pb_handle *h, const float *d_sum, size_t nfloat, float scale, uint8_t *d_codes,
+                                      hipStream_t st)
+{
+    const size_t nbytes = nfloat * h->cfg.nbit / 8;
+    if (h->cfg.nbit == 8 && (nfloat & 3) == 0) {
+        k_coadd_digitise8<<<256, 256, 0, st>>>((const float4 *)d_sum, scale, (uint32_t *)d_codes, nfloat / 4);
+        return hipGetLastError();
+    }
+    k_coadd_digitise<<<512, 256, 0, st>>>(d_sum, scale, d_codes, nfloat, nbytes, 1, 1, h->cfg.nbit, 0);
+    return hipGetLastError();
+}
+
 hipError_t launch_coadd_digitise(pb_handle *h, int nseg, const float *d_sum, float scale, uint8_t *d_codes,
                                  hipStream_t st)
 {

@@ -1367,6 +1367,19 @@ extern "C" int pb_coadd_release(pb_handle *h)
     return PB_OK;
 }
 
+// the two pinned / device slots the coadded bytes alternate between (allocated on first use)
+static int coadd_slots(pb_handle *h)
+{
+    const size_t nb = (size_t)h->S * h->trim;
+    if (!h->d_coadd_codes) {
+        HIPCHK(h, dmalloc(h, &h->d_coadd_codes, 2 * nb));
+        HIPCHK(h, hipHostMalloc((void **)&h->h_coadd_codes, 2 * nb, hipHostMallocDefault));
+        for (int i = 0; i < 2; ++i) HIPCHK(h, hipEventCreateWithFlags(&h->ev_coadd[i], hipEventDisableTiming));
+        h->coadd_slot = 0;
+    }
+    return PB_OK;
+}
+
 // Root side of the incoherent sum: scale by 1/sqrt(N), requantise on the GPU, bring the bytes to
 // pinned host memory asynchronously.  codes_host != NULL: wait and copy out (simple, blocking).
 // codes_host == NULL: return at once; the bytes of call k are read with pb_coadd_fetch_ptr after
@@ -1377,12 +1390,7 @@ extern "C" int pb_coadd_finish(pb_handle *h, int nseg, const float *d_sum, int n
     if (nseg < 1 || nseg > h->S) return fail(h, PB_EINVAL, "pb_coadd_finish: nseg out of range");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const size_t nb = (size_t)h->S * h->trim;
-    if (!h->d_coadd_codes) {
-        HIPCHK(h, dmalloc(h, &h->d_coadd_codes, 2 * nb));
-        HIPCHK(h, hipHostMalloc((void **)&h->h_coadd_codes, 2 * nb, hipHostMallocDefault));
-        for (int i = 0; i < 2; ++i) HIPCHK(h, hipEventCreateWithFlags(&h->ev_coadd[i], hipEventDisableTiming));
-        h->coadd_slot = 0;
-    }
+    if (int rc = coadd_slots(h)) return rc;
     const int slot = h->coadd_slot;
     h->coadd_slot ^= 1;
     h->coadd_last = slot;
@@ -1397,6 +1405,37 @@ extern "C" int pb_coadd_finish(pb_handle *h, int nseg, const float *d_sum, int n
         HIPCHK(h, hipEventSynchronize(h->ev_coadd[slot]));
         memcpy(codes_host, h->h_coadd_codes + slot * nb, (size_t)nseg * h->trim);
     }
+    return PB_OK;
+}
+
+// One rank's slice of the ordered sum, requantised where it was summed (coadd.py, "sliced" layout).
+extern "C" int pb_coadd_digitise(pb_handle *h, const float *d_sum, size_t nfloat, int nant_total, uint8_t *d_codes)
+{
+    if (!h || !d_sum || !d_codes || nant_total < 1) return PB_EINVAL;
+    if (h->cfg.npol != 1) return fail(h, PB_ESTATE, "pb_coadd_digitise: a flat plane range is a code range only with npol = 1");
+    if (nfloat == 0 || (nfloat & 7)) return fail(h, PB_EINVAL, "pb_coadd_digitise: nfloat must be a positive multiple of 8");
+    if (((uintptr_t)d_sum & 15) || ((uintptr_t)d_codes & 3)) return fail(h, PB_EINVAL, "pb_coadd_digitise: misaligned buffer");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t cs = h->s_coadd ? h->s_coadd : h->stream;
+    const float scale = (float)(1.0 / sqrt((double)nant_total));
+    HIPCHK(h, launch_coadd_digitise_flat(h, d_sum, nfloat, scale, d_codes, cs));
+    return PB_OK;
+}
+
+// The batch's coadded bytes, assembled on the device by the caller, to the pinned buffer pb_coadd_fetch_ptr hands out.
+extern "C" int pb_coadd_publish(pb_handle *h, const uint8_t *d_codes, size_t nbytes)
+{
+    if (!h || !d_codes) return PB_EINVAL;
+    const size_t nb = (size_t)h->S * h->trim;
+    if (nbytes == 0 || nbytes > nb) return fail(h, PB_EINVAL, "pb_coadd_publish: more bytes than a batch holds");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rc = coadd_slots(h)) return rc;
+    const int slot = h->coadd_slot;
+    h->coadd_slot ^= 1;
+    h->coadd_last = slot;
+    hipStream_t cs = h->s_coadd ? h->s_coadd : h->stream;
+    HIPCHK(h, launch_copy_out(h->sched, h->h_coadd_codes + slot * nb, d_codes, nbytes, cs));
+    HIPCHK(h, hipEventRecord(h->ev_coadd[slot], cs));
     return PB_OK;
 }
 

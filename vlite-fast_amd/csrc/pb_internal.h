@@ -187,6 +187,8 @@ hipError_t launch_pfb_weights(pb_handle *h, int nseg);
 hipError_t launch_pfb_history(pb_handle *h, int nseg);   // taps = 4: behind the weights, into the history slot the batch does not read
 hipError_t launch_channelize_f32(pb_handle *h, const float *d_x, int nrows, int taps, float2 *d_out);
 hipError_t launch_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate, hipStream_t st);
+hipError_t launch_coadd_digitise_flat(pb_handle *h, const float *d_sum, size_t nfloat, float scale, uint8_t *d_codes,
+                                      hipStream_t st);
 hipError_t launch_coadd_tree(const float *const *leaves, int n, float *d_dst, size_t nfloat, hipStream_t st);
 hipError_t launch_coadd_digitise(pb_handle *h, int nseg, const float *d_sum, float scale,
                                  uint8_t *d_codes, hipStream_t st);

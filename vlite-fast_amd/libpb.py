@@ -52,7 +52,7 @@ class PbTimers(C.Structure):
 EXPORTS = ["pb_config_default", "pb_create", "pb_destroy", "pb_last_error", "pb_query",
            "pb_set_stream", "pb_sync", "pb_reset_bandpass", "pb_reset_history", "pb_get_bandpass", "pb_set_bandpass",
            "pb_submit_planar", "pb_submit_planar_dev", "pb_submit_vdif", "pb_submit_vdif_at", "pb_input_dev", "pb_process", "pb_set_frb_params", "pb_select_set", "pb_fetch", "pb_fetch_ptr",
-           "pb_output_dev", "pb_coadd_local", "pb_coadd_local_codes", "pb_coadd_local_tree", "pb_coadd_tree", "pb_set_coadd_target", "pb_coadd_release", "pb_set_coadd_stream", "pb_coadd_finish", "pb_coadd_fetch_ptr", "pb_profile", "pb_get_timers", "pb_host_alloc", "pb_host_free",
+           "pb_output_dev", "pb_coadd_local", "pb_coadd_local_codes", "pb_coadd_local_tree", "pb_coadd_tree", "pb_coadd_digitise", "pb_coadd_publish", "pb_set_coadd_target", "pb_coadd_release", "pb_set_coadd_stream", "pb_coadd_finish", "pb_coadd_fetch_ptr", "pb_profile", "pb_get_timers", "pb_host_alloc", "pb_host_free",
            "pb_debug_fetch", "pb_debug_dag_check", "pb_channelize_f32", "pb_version", "pb_search_create", "pb_search_create_list", "pb_search_destroy",
            "pb_search_last_error", "pb_search_info", "pb_search_run", "pb_search_set_baseline", "pb_search_peaks",
            "pb_search_timers"]
@@ -108,6 +108,8 @@ def load():
     L.pb_coadd_local_codes.argtypes = [vp, C.c_int, vp, C.c_int]
     L.pb_coadd_local_tree.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.c_int, vp]
     L.pb_coadd_tree.argtypes = [vp, C.POINTER(vp), C.c_int, vp, C.c_size_t]
+    L.pb_coadd_digitise.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
+    L.pb_coadd_publish.argtypes = [vp, vp, C.c_size_t]
     L.pb_set_coadd_target.argtypes = [vp, vp]
     L.pb_coadd_release.argtypes = [vp]
     L.pb_set_coadd_stream.argtypes = [vp, vp]
@@ -318,6 +320,14 @@ class PbHandle(object):
         """d_dst[0..nfloat) = T_n over the caller's device planes leaf_ptrs (the root: the gathered partial sums)"""
         lv = (C.c_void_p * len(leaf_ptrs))(*[int(p) for p in leaf_ptrs])
         self._chk(self._L.pb_coadd_tree(self._h, lv, len(leaf_ptrs), C.c_void_p(d_dst_ptr), int(nfloat)))
+
+    def coadd_digitise(self, d_sum_ptr, nfloat, nant_total, d_codes_ptr):
+        """sel_and_dig of a flat range of the npol = 1 plane / sqrt(nant_total), device to device (a rank's slice)"""
+        self._chk(self._L.pb_coadd_digitise(self._h, C.c_void_p(d_sum_ptr), int(nfloat), int(nant_total), C.c_void_p(d_codes_ptr)))
+
+    def coadd_publish(self, d_codes_ptr, nbytes):
+        """the batch's coadded bytes (assembled on the device) -> the pinned buffer coadd_view hands out"""
+        self._chk(self._L.pb_coadd_publish(self._h, C.c_void_p(d_codes_ptr), int(nbytes)))
 
     def set_coadd_target(self, d_sum_ptr):
         """nant = 1: the selected set's detect writes the plane to be reduced straight into d_sum (0 / None: off);
