@@ -827,8 +827,12 @@ def main():
             out["reduce_leg"] = r.get("reduce_leg")
             out["coadd_order"] = {"order": args.coadd_order, "layout": r.get("coadd_layout"),
                                   "meaning": ("antennas split by index parity, recursively (DESIGN.md section 6): every rank's "
-                                              "node by pb_coadd_local_tree, one fp32 plane per rank gathered to rank 0, "
-                                              "pb_coadd_tree there; bytes independent of the number of GPUs")
+                                              "node by pb_coadd_local_tree; " +
+                                              ("an all-to-all of plane slices, every rank evaluates the top levels "
+                                               "(pb_coadd_tree) and requantises (pb_coadd_digitise) 1/N of the plane, code "
+                                               "bytes gathered to rank 0" if r.get("coadd_layout") == "sliced" else
+                                               "one fp32 plane per rank gathered to rank 0, pb_coadd_tree + requantisation "
+                                               "there") + "; bytes independent of the number of GPUs")
                                   if args.coadd_order == "tree" else
                                   "left-to-right local sums, one RCCL reduce(SUM): association left to the collective"}
             # one rank per GPU, all of them in the group: anything else is not the run the line claims to be
@@ -845,9 +849,11 @@ def main():
                                "product": "vlite-fast_amd/coadd_host.py runs this leg (coadd.IncoherentCoadd) on antenna "
                                           "dumps / rings and writes the one station-99 .fil",
                                "note": "BASELINE configs[3] (16 antennas on 8 GPUs): %d antennas here, 2 per GPU, the fp32 "
-                                       "planes summed in the order \"%s\" (%s) on rank 0, which requantises the "
-                                       "coadded second" % (c3["nant_total"], args.coadd_order,
-                                                           "local tree, gather, root tree" if args.coadd_order == "tree"
+                                       "planes summed in the order \"%s\" (%s); rank 0 hands out the coadded "
+                                       "second" % (c3["nant_total"], args.coadd_order,
+                                                           ("local tree, all-to-all of slices, every rank sums and requantises "
+                                                            "its share, codes gathered" if c3.get("coadd_layout") == "sliced"
+                                                            else "local tree, gather, root tree") if args.coadd_order == "tree"
                                                            else "local sum, one reduce")}
         if world == 1:
             try:
