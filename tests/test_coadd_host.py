@@ -320,6 +320,38 @@ def test_coadd_host_refuses_colliding_station_ids(tmp_path, monkeypatch):
         assert not (d / "20160701_010000_muos_ea07.fil").exists()
 
 
+def test_coadd_host_honours_the_source_list_with_w1(tmp_path, monkeypatch):
+    """-w 1 (src/process_baseband.cu:880-923, per antenna here): an antenna whose source is on the site's list gets
+    its .fil / _kur.fil, one whose source is not writes to /dev/null; the coadded file is written either way."""
+    vdif, sigproc, dada, coadd, host = _mods()
+    import torch
+    lst = tmp_path / "allow.txt"
+    lst.write_text("name B0833\n")
+    monkeypatch.setenv("PB_WRITE_ALLOW", str(lst))
+    args = host.build_parser().parse_args(["--replay", "a", "b", "-b", "8", "-r", "2", "-w", "1", "--datadir", str(tmp_path),
+                                           "--logdir", str(tmp_path / "logs"), "--rows-per-seg", str(R), "--dist-backend", "gloo"])
+    rings = {}
+    for a in range(2):
+        hdr, body = _stream(a)
+        if a == 1:
+            hdr = hdr.replace(b"B0833-45", b"J0000+00")
+            assert b"J0000+00" in hdr and len(hdr) == 4096
+        r = dada.MemoryRing()
+        r.write_header(hdr)
+        r.write(np.frombuffer(body, np.uint8))
+        r.end_of_data()
+        rings[a] = r
+    h = FakeCoaddHandle(2, nsets=2)
+    co = coadd.IncoherentCoadd(h, 2, torch.device("cpu"), backend="gloo")
+    assert host.run(args, rank=0, world=1, rings=rings, handle=h, device=torch.device("cpu"), coadd=co) == 0
+    assert (tmp_path / ("20160701_010000_muos_ea%02d_kur.fil" % STATIONS[0])).stat().st_size > 1000
+    assert not (tmp_path / ("20160701_010000_muos_ea%02d_kur.fil" % STATIONS[1])).exists()
+    assert not (tmp_path / ("20160701_010000_muos_ea%02d.fil" % STATIONS[1])).exists()
+    assert (tmp_path / "20160701_010000_muos_ea99_kur.fil").stat().st_size > 1000
+    log = "".join(p.read_text() for p in (tmp_path / "logs").iterdir())
+    assert "matches target list" in log and "not on target list" in log
+
+
 def test_incoherent_coadd_source_switch():
     """IncoherentCoadd(source=...): "planes" queues pb_coadd_local, "codes" pb_coadd_local_codes (and never the
     coadd-target shortcut, which hands detect's fp32 plane to the reduce); anything else is refused.  One process,
