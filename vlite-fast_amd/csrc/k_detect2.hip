@@ -454,6 +454,8 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
                 for (int j = 0; j < T; ++j) pk[j] = s_p[slot][j][lane];
                 s_u0[buf][lane] = bp;
                 float t1 = scale * pk[0];
+                // (The quads are EARLY-CLOBBER outputs: a row writes its bp while later rows of the block still read their
+                //  inputs, so no input may be allocated inside the quad.)
                 // Four rows per asm block, in FIXED registers: the bp after each row goes straight into the quad that the
                 // 16-byte LDS store takes (v[56:59] and v[60:63] alternate; a row reads its predecessor's bp where that
                 // row left it), so no copy per row; the excised stream's two products with bp -- (1-s) bp and 11 bp --
@@ -488,7 +490,7 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
                                          D2_ROW_RAW("v56", "v57", "%[ta]", "%[tb]", "%[p2]")
                                          D2_ROW_RAW("v57", "v58", "%[tb]", "%[ta]", "%[p3]")
                                          D2_ROW_RAW("v58", "v59", "%[ta]", "%[tn]", "%[p4]")
-                                         : "={v[56:59]}"(o), [ta] "=&v"(ta), [tb] "=&v"(tb), [tn] "=&v"(t1n)
+                                         : "=&{v[56:59]}"(o), [ta] "=&v"(ta), [tb] "=&v"(tb), [tn] "=&v"(t1n)
                                          : "{v63}"(bp), [sp0] "v"(t1), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [p4] "v"(p4),
                                            [sc] "v"(scale), [om] "v"(oms)
                                          : "v54");
@@ -497,7 +499,7 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
                                          D2_ROW_RAW("v60", "v61", "%[ta]", "%[tb]", "%[p2]")
                                          D2_ROW_RAW("v61", "v62", "%[tb]", "%[ta]", "%[p3]")
                                          D2_ROW_RAW("v62", "v63", "%[ta]", "%[tn]", "%[p4]")
-                                         : "={v[60:63]}"(o), [ta] "=&v"(ta), [tb] "=&v"(tb), [tn] "=&v"(t1n)
+                                         : "=&{v[60:63]}"(o), [ta] "=&v"(ta), [tb] "=&v"(tb), [tn] "=&v"(t1n)
                                          : "{v59}"(bp), [sp0] "v"(t1), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [p4] "v"(p4),
                                            [sc] "v"(scale), [om] "v"(oms)
                                          : "v54");
@@ -511,7 +513,7 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
                                          D2_ROW_KUR("v[56:57]", "0", "v56", "v57", "%[ta]", "%[p1]", "%[tb]", "%[p2]")
                                          D2_ROW_KUR("v[56:57]", "1", "v57", "v58", "%[tb]", "%[p2]", "%[ta]", "%[p3]")
                                          D2_ROW_KUR("v[58:59]", "0", "v58", "v59", "%[ta]", "%[p3]", "%[tn]", "%[p4]")
-                                         : "={v[56:59]}"(o), [ta] "=&v"(ta), [tb] "=&v"(tb), [tn] "=&v"(t1n)
+                                         : "=&{v[56:59]}"(o), [ta] "=&v"(ta), [tb] "=&v"(tb), [tn] "=&v"(t1n)
                                          : "{v63}"(bp), [sp0] "v"(t1), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3),
                                            [p4] "v"(p4), [sc] "v"(scale), [cf] "v"(coef)
                                          : "vcc", "v54", "v55", "v62");
@@ -520,7 +522,7 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
                                          D2_ROW_KUR("v[60:61]", "0", "v60", "v61", "%[ta]", "%[p1]", "%[tb]", "%[p2]")
                                          D2_ROW_KUR("v[60:61]", "1", "v61", "v62", "%[tb]", "%[p2]", "%[ta]", "%[p3]")
                                          D2_ROW_KUR("v[62:63]", "0", "v62", "v63", "%[ta]", "%[p3]", "%[tn]", "%[p4]")
-                                         : "={v[60:63]}"(o), [ta] "=&v"(ta), [tb] "=&v"(tb), [tn] "=&v"(t1n)
+                                         : "=&{v[60:63]}"(o), [ta] "=&v"(ta), [tb] "=&v"(tb), [tn] "=&v"(t1n)
                                          : "{v59}"(bp), [sp0] "v"(t1), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3),
                                            [p4] "v"(p4), [sc] "v"(scale), [cf] "v"(coef)
                                          : "vcc", "v54", "v55", "v58");
