@@ -215,6 +215,9 @@ int pb_coadd_local_codes(pb_handle *h, int nseg, float *d_sum, int accumulate);
  * n <= PB_COADD_MAX_LEAVES; planes 16-byte aligned, nfloat a multiple of 4.  Which plane is which leaf is the host's
  * business (vlite-fast_amd/coadd.py: tree_order); pb_coadd_finish(d_dst) follows on the root. */
 #define PB_COADD_MAX_LEAVES 32
+/* the leaf order of that tree over 0 .. n-1 (even positions first, recursively: 0 | 0 1 | 0 2 1 | 0 2 1 3 | 0 4 2 1 3 |
+ * ... ; bit reversal when n is a power of two): order[0..n) for 1 <= n <= PB_COADD_MAX_LEAVES.  Host only, no handle. */
+int pb_coadd_tree_order(int n, int32_t *order);
 int pb_coadd_local_tree(pb_handle *h, int nseg, const int32_t *ant_order, int n, float *d_dst);
 int pb_coadd_tree(pb_handle *h, const float *const *d_leaves, int n, float *d_dst, size_t nfloat);
 /* The root's work spread over the ranks ("sliced" layout of the ordered sum, coadd.py): every rank sums and

@@ -87,3 +87,17 @@ def test_shipped_library_holds_no_result_invalidating_switch():
     i = txt.index('getenv("PB_SKIP")')
     assert "#if PB_EXPERIMENTS" in txt[max(0, i - 200):i]       # the one PB_SKIP read sits behind the build switch
     assert txt.count('getenv("PB_SKIP")') == 2                   # (both on that one line)
+
+
+def test_tree_order_of_the_library_equals_the_python_plan():
+    """pb_coadd_tree_order (for hosts written in C) == coadd.tree_order for every leaf count; host
+    code only, no GPU"""
+    import importlib
+    lp = libpb()
+    L = lp.load()
+    coadd = importlib.import_module("vlite-fast_amd.coadd")
+    for n in range(1, 33):
+        out = (C.c_int32 * n)()
+        assert L.pb_coadd_tree_order(n, out) == 0
+        assert list(out) == coadd.tree_order(range(n)), n
+    assert L.pb_coadd_tree_order(33, (C.c_int32 * 33)()) == -22 and L.pb_coadd_tree_order(0, (C.c_int32 * 1)()) == -22

@@ -1282,6 +1282,30 @@ extern "C" int pb_coadd_local_codes(pb_handle *h, int nseg, float *d_sum, int ac
     return PB_OK;
 }
 
+// leaves of S over items[0..n) left to right: the even positions' subtree, then the odd positions'
+static void tree_order_rec(const int32_t *items, int n, int32_t *&out)
+{
+    if (n <= 1) {
+        if (n == 1) *out++ = items[0];
+        return;
+    }
+    int32_t ev[PB_COADD_MAX_LEAVES], od[PB_COADD_MAX_LEAVES];
+    int ne = 0, no = 0;
+    for (int i = 0; i < n; ++i) (i & 1 ? od[no++] : ev[ne++]) = items[i];
+    tree_order_rec(ev, ne, out);
+    tree_order_rec(od, no, out);
+}
+
+extern "C" int pb_coadd_tree_order(int n, int32_t *order)
+{
+    if (!order || n < 1 || n > PB_COADD_MAX_LEAVES) return PB_EINVAL;
+    int32_t items[PB_COADD_MAX_LEAVES];
+    for (int i = 0; i < n; ++i) items[i] = i;
+    int32_t *out = order;
+    tree_order_rec(items, n, out);
+    return PB_OK;
+}
+
 // The incoherent sum in the defined order (coadd_tree.hip): one rank's node of the tree from
 // the selected set's fp32 planes, ordered against detect and the set's next batch exactly like pb_coadd_local.
 extern "C" int pb_coadd_local_tree(pb_handle *h, int nseg, const int32_t *ant_order, int n, float *d_dst)

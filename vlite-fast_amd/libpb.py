@@ -52,7 +52,7 @@ class PbTimers(C.Structure):
 EXPORTS = ["pb_config_default", "pb_create", "pb_destroy", "pb_last_error", "pb_query",
            "pb_set_stream", "pb_sync", "pb_reset_bandpass", "pb_reset_history", "pb_get_bandpass", "pb_set_bandpass",
            "pb_submit_planar", "pb_submit_planar_dev", "pb_submit_vdif", "pb_submit_vdif_at", "pb_input_dev", "pb_process", "pb_set_frb_params", "pb_select_set", "pb_fetch", "pb_fetch_ptr",
-           "pb_output_dev", "pb_coadd_local", "pb_coadd_local_codes", "pb_coadd_local_tree", "pb_coadd_tree", "pb_coadd_digitise", "pb_coadd_publish", "pb_set_coadd_target", "pb_coadd_release", "pb_set_coadd_stream", "pb_coadd_finish", "pb_coadd_fetch_ptr", "pb_profile", "pb_get_timers", "pb_host_alloc", "pb_host_free",
+           "pb_output_dev", "pb_coadd_local", "pb_coadd_local_codes", "pb_coadd_local_tree", "pb_coadd_tree", "pb_coadd_tree_order", "pb_coadd_digitise", "pb_coadd_publish", "pb_set_coadd_target", "pb_coadd_release", "pb_set_coadd_stream", "pb_coadd_finish", "pb_coadd_fetch_ptr", "pb_profile", "pb_get_timers", "pb_host_alloc", "pb_host_free",
            "pb_debug_fetch", "pb_debug_dag_check", "pb_channelize_f32", "pb_version", "pb_search_create", "pb_search_create_list", "pb_search_destroy",
            "pb_search_last_error", "pb_search_info", "pb_search_run", "pb_search_set_baseline", "pb_search_peaks",
            "pb_search_timers"]
@@ -108,6 +108,7 @@ def load():
     L.pb_coadd_local_codes.argtypes = [vp, C.c_int, vp, C.c_int]
     L.pb_coadd_local_tree.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.c_int, vp]
     L.pb_coadd_tree.argtypes = [vp, C.POINTER(vp), C.c_int, vp, C.c_size_t]
+    L.pb_coadd_tree_order.argtypes = [C.c_int, C.POINTER(C.c_int32)]
     L.pb_coadd_digitise.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
     L.pb_coadd_publish.argtypes = [vp, vp, C.c_size_t]
     L.pb_set_coadd_target.argtypes = [vp, vp]
