@@ -26,6 +26,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import hashlib
+import re
 import importlib
 import json
 import os
@@ -276,11 +277,40 @@ def valu_record(args, taps, ms_per_step, gfx_mhz):
             "frac": round(cyc / N_SIMD / step_cycles, 4), "source": mv["source"]}
 
 
+def residency_record():
+    """What bounds the step, from the committed co-runner decomposition (tools/corun_probe.py, profiles/r05_notes.md
+    section 1): the channeliser's per-launch time alone, beside 256 SLEEPING workgroups that only hold the 57 KB of LDS
+    a detect workgroup takes (one per CU), and beside the real detect, with the socket power of each.  Not measured by
+    this run (the probe needs the experiments build): the figures and their source file are quoted."""
+    path = os.path.join(ROOT, "profiles", "r05_corun_probe.txt")
+    try:
+        rows = {}
+        skip = None
+        for line in open(path):
+            if line.startswith("PB_SKIP="):
+                skip = line.split()[0].split("=")[1]
+            m = re.match(r"^(\S.*?)\s+step ([0-9.]+) ms\s+channelize ([0-9.]+) ms/launch\s+detect ([0-9.]+)\s+([0-9.]+) W\s+([0-9.]+) J/step", line)
+            if m:
+                rows.setdefault((skip, m.group(1).strip()), []).append((float(m.group(3)), float(m.group(5)), float(m.group(6))))
+        alone = rows[("2", "none")][-1]
+        held = rows[("2", "hold 256 384 58368")][-1]
+        pipe = rows[("0", "none")][-1]
+        return {"channelize_ms_per_launch": {"alone": alone[0], "beside_256_sleeping_57KB_workgroups": held[0], "beside_detect": pipe[0]},
+                "socket_w": {"alone": alone[1], "beside_256_sleeping_57KB_workgroups": held[1], "beside_detect": pipe[1]},
+                "bound": "residency: three channeliser workgroups use 504 of 512 VGPRs per SIMD lane and 150 of 160 KB of LDS; a "
+                         "detect workgroup per CU takes the place of one (x 1.35 - 1.4), at a socket power 300 W below the cap",
+                "source": "profiles/r05_corun_probe.txt (tools/corun_probe.py + tools/corun.hip, experiments build; quoted, not "
+                          "re-measured by this run)"}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
 def power_record(torch, lp, args, dev, local, taps, seconds=2.0):
     """What the package does while the pipeline runs: socket power against its cap, the XCDs' clocks and the share of
     the time the firmware spent throttling for package power (amdsmi GPU metrics, ppt_residency_acc against
-    accumulation_counter), over `seconds` of untimed steps.  Reported because it is the bound the kernels run
-    into: both pipes are under half busy, HBM at a third, and the chip sits at its power cap."""
+    accumulation_counter), over `seconds` of untimed steps.  Reported because the chip sits at its power cap while the
+    pipeline runs; that costs the 10 - 12 % of clock it shows, while the step itself is bound by how many workgroups a
+    CU holds (`roofline.residency`, profiles/r05_notes.md)."""
     try:
         import amdsmi
         import threading
@@ -865,6 +895,7 @@ def main():
                     out["roofline"]["power"] = power_record(torch, lp, args, dev, local, args.taps)
                 except Exception as e:
                     out["roofline"]["power"] = {"error": str(e)}
+            out["roofline"]["residency"] = residency_record()
             try:
                 pw = out["roofline"].get("power") or {}
                 out["roofline"]["valu"] = valu_record(args, args.taps, r["ms_per_step"], pw.get("gfx_mhz"))
