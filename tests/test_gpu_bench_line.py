@@ -43,6 +43,11 @@ def test_bench_line_fields_and_consistency():
     if "error" not in pw:                   # (amdsmi may be unavailable to an unprivileged user on some hosts)
         assert 300 < pw["socket_w"] <= pw["cap_w"] * 1.02 and pw["cap_w"] >= 500
         assert 500 <= pw["gfx_mhz"] <= 2500 and 0.0 <= pw["power_throttle_residency"] <= 1.0
+    rs = r["residency"]                     # (round 5: the committed co-runner decomposition, quoted in the line)
+    assert "error" not in rs, rs
+    cm = rs["channelize_ms_per_launch"]
+    assert cm["alone"] < cm["beside_256_sleeping_57KB_workgroups"] <= cm["beside_detect"] * 1.02
+    assert rs["socket_w"]["beside_256_sleeping_57KB_workgroups"] < rs["socket_w"]["alone"] - 100
     v = r["valu"]
     if v is not None:                       # (None when no committed PMC summary matches the kernels' source hash)
         assert "error" not in v, v
