@@ -455,7 +455,7 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
         leg = cmod.IncoherentCoadd(h, nant_total, dev, root=0, backend=args.dist_backend, order=args.coadd_order,
                                    layout=args.coadd_layout, parts=int(os.environ.get("PB_COADD_PARTS", "7")))     # (parts: timing experiments)
         if world == 1 and getattr(args, "emulate_world", 0) > 1:
-            leg.emulate_root_of(args.emulate_world, dev)
+            leg.emulate_root_of(args.emulate_world, dev, layout="sliced" if args.coadd_layout != "root" else "root")
     nstream_out = (0, 1) if args.rfi_mode == 2 else ((0,) if args.rfi_mode == 0 else (1,))
     state = {"k": 0, "sink": 0, "coadds": 0}
 
@@ -814,6 +814,7 @@ def main():
         print(json.dumps({"coadd_selftest": {"ms_per_step_plain": round(plain["ms_per_step"], 4),
                                              "ms_per_step_with_coadd_leg": round(withc["ms_per_step"], 4),
                                              "emulated_world": args.emulate_world or 1, "antennas_per_gpu": A,
+                                             "emulated_layout": ("sliced" if args.coadd_layout != "root" else "root") if args.emulate_world > 1 else None,
                                              "stage_ms_per_step": withc["stage_ms_per_step"]}}))
         dist.destroy_process_group()
         return

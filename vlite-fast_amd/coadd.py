@@ -281,7 +281,11 @@ class IncoherentCoadd(object):
                 return
             if self.parts & 2 and self.world > 1:
                 self._collective(ds)
-            if self.emulate is not None:
+            if self.emulate is not None and self.emulate[0] == "sliced":
+                _, leaves, tot, codes, W = self.emulate
+                h.coadd_tree(leaves, tot.data_ptr(), nfl // W)
+                h.coadd_digitise(tot.data_ptr(), nfl // W, self.nant_total, codes.data_ptr())
+            elif self.emulate is not None:
                 h.coadd_tree(self.emulate[1], self.emulate[2].data_ptr(), nfl)
                 final = self.emulate[2]
             if self.rank == self.root and self.parts & 4:
@@ -293,8 +297,17 @@ class IncoherentCoadd(object):
                 h.coadd_release()
         self.queued += 1
 
-    def emulate_root_of(self, W, device):
-        """timing only: queue() also runs the root's tree over W planes of this size (see __init__)"""
+    def emulate_root_of(self, W, device, layout="root"):
+        """timing only: queue() also runs the device work a W-rank world adds -- "root": rank 0's tree over W gathered
+        planes; "sliced": EVERY rank's tree over W slices of 1/W of the plane and the slice's requantisation (then the
+        coadded bytes are this handle's own, requantised by pb_coadd_finish as in a world of one)"""
+        if layout == "sliced":
+            g = torch.zeros(self.n, dtype=torch.float32, device=device)
+            sl = self.n // W
+            tot = torch.zeros(sl, dtype=torch.float32, device=device)
+            codes = torch.zeros(sl, dtype=torch.uint8, device=device)
+            self.emulate = ("sliced", [g.data_ptr() + 4 * sl * r for r in tree_order(range(W))], tot, codes, W)
+            return
         g = torch.zeros(W * self.n, dtype=torch.float32, device=device)
         tot = torch.zeros(self.n, dtype=torch.float32, device=device)
         self.emulate = (g, [g.data_ptr() + 4 * self.n * r for r in tree_order(range(W))], tot)
