@@ -199,6 +199,14 @@ def test_incoherent_coadd_leg_world1_rccl_gather_path():
         dist.gather(src, [g], dst=0)
         torch.cuda.synchronize()
         assert torch.equal(g, src)
+        # ... and the sliced layout's collectives as RCCL calls (one rank: identity): all_to_all_single on fp32, gather on uint8
+        g2 = torch.zeros_like(src)
+        dist.all_to_all_single(g2, src)
+        cb = (torch.arange(4096, device=dev) % 251).to(torch.uint8)
+        cg = torch.zeros_like(cb)
+        dist.gather(cb, [cg], dst=0)
+        torch.cuda.synchronize()
+        assert torch.equal(g2, src) and torch.equal(cg, cb)
         leg.close()
         h.coadd_local_tree(S, [0, 1], g.data_ptr())          # the handle is usable after the leg has gone
         h.sync()
