@@ -174,12 +174,13 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
     auto load_t2 = [&]() {
         if (tid < 250) {
 #pragma unroll
-            // table layout [k][r = 1..24]: a thread's 24 twiddles are 192 contiguous bytes, fetched two
-            // per 16-byte load (vector-memory instructions, not bytes, are what the channeliser is short
-            // of: 12 loads here instead of 24)
+            // table layout [pair (r, r+1) = 12][k = 25] of 16 bytes (round 5; it was [k][r]): two twiddles per 16-byte
+            // load, and the 25 distinct k of a wave's lanes read 400 contiguous bytes = 4 cache lines per instruction
+            // instead of 25 (one 192-byte row per k).  The L1 works through a wave's load line by line: with three
+            // workgroups per CU the twiddle loads kept it busy for more than half of the time (profiles/r05_notes.md)
             for (int r = 1; r < 25; r += 2) {
                 typedef float f4 __attribute__((ext_vector_type(4)));
-                const f4 q = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs2, k * 192, (r - 1) * 8, 0));
+                const f4 q = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs2, k * 16, ((r - 1) / 2) * (25 * 16), 0));
                 t2[r - 1] = mk2(q.x, q.y);
                 t2[r] = mk2(q.z, q.w);
             }

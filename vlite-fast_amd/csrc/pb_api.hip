@@ -221,9 +221,12 @@ static float2 cis_neg(double num, double den)
 static int build_fft_tables(pb_handle *h)
 {
     std::vector<float2> tw2(600), tw3(6250), post(PB_NCHAN);
-    // per-thread contiguous layouts (fft_lds.h): tw2[k][r-1], r = 1..24; tw3[j][r-1], r = 1..9 (+ 1 pad)
+    // fft_lds.h's layouts.  tw2[pair = (r-1)/2][k][2], r = 1..24: twiddles (r, r + 1) as one 16-byte entry with the lane's
+    // k fastest, so a wave's load touches 4 cache lines, not one 192-byte row per k.  tw3[j][r-1], r = 1..9 (+ 1 pad):
+    // per-thread contiguous (the same re-layout of tw3 gains as much again but costs the two-kernel channeliser a
+    // register spill, profiles/r05_notes.md)
     for (int k = 0; k < 25; ++k)
-        for (int r = 1; r < 25; ++r) tw2[k * 24 + (r - 1)] = cis_neg((double)(r * k), 625.0);
+        for (int r = 1; r < 25; ++r) tw2[(((r - 1) / 2) * 25 + k) * 2 + ((r - 1) & 1)] = cis_neg((double)(r * k), 625.0);
     for (int j = 0; j < 625; ++j) {
         for (int r = 1; r < 10; ++r) tw3[j * 10 + (r - 1)] = cis_neg((double)(r * j), 6250.0);
         tw3[j * 10 + 9] = make_float2(0.f, 0.f);
