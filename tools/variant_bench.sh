@@ -2,6 +2,7 @@
 # bench.py over the variant libraries of tools/build_variants.sh; prints per-stage ms per step.
 # usage: tools/variant_bench.sh out.txt [bench args --] name1 name2 ...   (name "base" = the tree's library)
 out=$1; shift
+mkdir -p "$(dirname "$out")"
 extra=""
 while [ "$1" != "--" ] && [ $# -gt 0 ]; do extra="$extra $1"; shift; done
 shift
