@@ -58,26 +58,34 @@ def test_product_does_not_import_oracle():
                 assert not bad.search(txt), fn
 
 
-def test_shipped_library_holds_no_result_invalidating_switch():
-    """Switches whose effect is "results invalid" (PB_SKIP: a kernel left out; PB_PFB_DBG: flags from stale bytes)
-    exist in experiment builds only (`make exp` / tools/build_variants.sh, selected with PB_LIBPATH): the shipped
-    library -- and the native host program -- do not even contain the variables' names, so no environment can make a
-    production host write garbage.  Every getenv the library does make is of a switch that leaves results unchanged
-    (scheduling and timing choices, each covered by tests/test_gpu_schedules.py)."""
+SHIPPED_SWITCHES = {"PB_FUSE_KURTOSIS", "PB_KUR_EARLY", "PB_OVERLAP_DETECT", "PB_DETECT_DEPTH", "PB_DAG_BANDS"}
+
+
+def test_shipped_library_reads_exactly_the_documented_switches():
+    """Switches whose effect is "results invalid" (PB_SKIP: a kernel left out; PB_PFB_DBG: flags from stale bytes) and
+    the switches that only ever served one timing experiment (PB_COPY_DMA, PB_COPY_WGS, PB_DET_CUS, PB_DET_PRIO) exist in
+    experiment builds only (`make exp` / tools/build_variants.sh, selected with PB_LIBPATH): the shipped library -- the
+    ONE product library, there is no other flavour beside it -- and the native host program do not even contain the
+    variables' names, so no environment can make a production host write garbage.  What libpb_hip.so does read is
+    exactly SHIPPED_SWITCHES (scheduling choices that leave results unchanged, each covered by
+    tests/test_gpu_schedules.py or tests/test_gpu_parity.py), which is also the table in INTEGRATION.md."""
     import re
     csrc = os.path.join(ROOT, "vlite-fast_amd", "csrc")
-    forbidden = (b"PB_SKIP", b"PB_PFB_DBG", b"CH_ABL", b"FFT_ABL", b"D2_ABL")
-    for fn in ("libpb_hip.so", "libpb_hip_fg.so", "process_baseband"):
+    forbidden = (b"PB_SKIP", b"PB_PFB_DBG", b"CH_ABL", b"FFT_ABL", b"D2_ABL", b"PB_COPY_DMA", b"PB_COPY_WGS", b"PB_DET_CUS",
+                 b"PB_DET_PRIO", b"PB_FINE_GRAINED", b"PB_LEAN_LDS")
+    for fn in ("libpb_hip.so", "process_baseband"):
         path = os.path.join(csrc, fn)
-        if not os.path.exists(path):
-            assert fn != "libpb_hip.so"
-            continue
+        assert os.path.exists(path), fn
         blob = open(path, "rb").read()
         for name in forbidden:
             assert name not in blob, "%s contains %s" % (fn, name.decode())
-    # and the sources read the environment only through names on this list
-    allowed = {"PB_LEAN_LDS", "PB_COPY_DMA", "PB_COPY_WGS", "PB_DETECT_DEPTH", "PB_FINE_GRAINED", "PB_OVERLAP_DETECT",
-               "PB_DET_CUS", "PB_DET_PRIO", "PB_FUSE_KURTOSIS", "PB_KUR_EARLY", "PB_DAG_BANDS", "PB_SKIP"}
+    blob = open(os.path.join(csrc, "libpb_hip.so"), "rb").read()
+    in_lib = set(m.decode() for m in re.findall(rb"PB_[A-Z][A-Z0-9_]{3,}(?=\x00)", blob))
+    env_like = set(n for n in in_lib if not n.startswith(("PB_ST_", "PB_FFT_", "PB_E", "PB_OK")))
+    assert env_like == SHIPPED_SWITCHES, env_like ^ SHIPPED_SWITCHES
+    assert not os.path.exists(os.path.join(csrc, "libpb_hip_fg.so")), "the fine-grained variant is a patch under tools/experiments"
+    # and the sources read the environment only through names on this list (the second set: experiments build only)
+    allowed = SHIPPED_SWITCHES | {"PB_LEAN_LDS", "PB_COPY_DMA", "PB_COPY_WGS", "PB_DET_CUS", "PB_DET_PRIO", "PB_SKIP"}
     seen = set()
     for fn in os.listdir(csrc):
         if fn.endswith((".hip", ".h")):
@@ -87,6 +95,12 @@ def test_shipped_library_holds_no_result_invalidating_switch():
     i = txt.index('getenv("PB_SKIP")')
     assert "#if PB_EXPERIMENTS" in txt[max(0, i - 200):i]       # the one PB_SKIP read sits behind the build switch
     assert txt.count('getenv("PB_SKIP")') == 2                   # (both on that one line)
+    for name in ("PB_COPY_DMA", "PB_COPY_WGS", "PB_DET_CUS", "PB_DET_PRIO"):
+        i = txt.index('env_int("%s"' % name)
+        assert "#if PB_EXPERIMENTS" in txt[max(0, i - 400):i], name
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name in SHIPPED_SWITCHES:
+        assert "| `%s` |" % name in doc, name
 
 
 def test_tree_order_of_the_library_equals_the_python_plan():

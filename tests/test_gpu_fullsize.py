@@ -157,24 +157,3 @@ def test_fullsize_two_antennas_per_gpu_bit_exact_vs_oracle(oracle):
     got, bps = _run_pipelined_fullsize(lp, d, 2, nsets, nseg, nb)
     for a in range(2):
         _assert_equals_oracle(oracle, d[a], got[a], bps[a])
-
-
-def test_fine_grained_coupling_is_bit_exact_too():
-    """libpb_hip_fg.so (`make -C vlite-fast_amd/csrc fg`; not the shipped library: measured slower, profiles/r04_notes.md):
-    detect starts beside the channeliser of its own batch and follows it chunk by chunk through the row-ready counters
-    (planes written through to the fabric, system-scope loads).  The headline test and the 32-row-chunk pipelined test
-    pass unchanged in a process that loads that library."""
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    lib = os.path.join(os.path.dirname(here), "vlite-fast_amd", "csrc", "libpb_hip_fg.so")
-    if os.environ.get("PB_LIBPATH", "").endswith("libpb_hip_fg.so"):
-        pytest.skip("already inside the run that loads it")
-    if not os.path.exists(lib):
-        pytest.skip("libpb_hip_fg.so not built (make -C vlite-fast_amd/csrc fg)")
-    env = dict(os.environ, PB_LIBPATH=lib)
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.join(here, "test_gpu_fullsize.py"), os.path.join(here, "test_gpu_parity.py"),
-                        "-k", "headline_path or pipelined_sets_with_32_row_chunks"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-    assert r.returncode == 0, r.stdout.decode()[-3000:]
-    assert b"passed" in r.stdout

@@ -6,7 +6,7 @@ of one antenna each) through
     x  the kurtosis pass beside or behind the previous channeliser (PB_KUR_EARLY; three sets, two kernels)
     x  input resident in the sets' buffers (pb_input_dev / nothing staged between calls, as bench.py runs) or
        re-staged before every call (device-to-device, or from host memory)
-    +  detect's ring two / three chunks deep (PB_DETECT_DEPTH), the copy-out by DMA (PB_COPY_DMA), taps = 4
+    +  detect's ring two / three chunks deep (PB_DETECT_DEPTH), taps = 4
 must give IDENTICAL bytes for every batch, both streams, and the same final bandpass state: none of these switches may
 change a result, and an ordering hole in the graph -- a wait dropped by the next overlap trick --
 shows up here as a difference.  The first mode's first two segments are also compared with the oracle, so "identical"
@@ -51,7 +51,6 @@ def _modes():
     out.append(dict(nsets=3, fuse=1, feed="resident", overlap=1, kur_early=1, depth=2))
     out.append(dict(nsets=3, fuse=1, feed="resident", overlap=1, kur_early=1, depth=3))
     out.append(dict(nsets=2, fuse=0, feed="staged", overlap=1, kur_early=1, depth=3))
-    out.append(dict(nsets=3, fuse=1, feed="resident", overlap=1, kur_early=1, copy_dma=1))
     out.append(dict(nsets=3, fuse=1, feed="host", overlap=1, kur_early=1))
     out.append(dict(nsets=2, fuse=0, feed="host", overlap=0, kur_early=1))
     return out
@@ -64,7 +63,6 @@ def _run(lp, monkeypatch, x, mode, taps=1, host=None):
     monkeypatch.setenv("PB_KUR_EARLY", str(mode["kur_early"]))
     monkeypatch.setenv("PB_FUSE_KURTOSIS", str(mode["fuse"]))
     monkeypatch.setenv("PB_DETECT_DEPTH", str(mode.get("depth", 0)))
-    monkeypatch.setenv("PB_COPY_DMA", str(mode.get("copy_dma", 0)))
     nsets = mode["nsets"]
     A = mode.get("nant", 1)
     raw, kur = [], []

@@ -347,15 +347,8 @@ __device__ __forceinline__ void read_z_pairs(const f2 *buf, int k0, f2 (&za)[4],
 // Power-plane stores.  PB_NT_STORES: as streaming (non-temporal) stores -- 671 MB per launch of planes that
 // nobody on this die reads again pass through a 4-MB L2 and push out the rows' bytes that a workgroup requests a
 // second time 20 us later.
-#ifndef PB_NT_STORES      // 0 ordinary, 1 non-temporal, 2 written through to the fabric at system scope (store_plane4)
-#if PB_FG
-#define PB_NT_STORES 2
-#else
+#ifndef PB_NT_STORES      // 0 ordinary, 1 non-temporal
 #define PB_NT_STORES 1
-#endif
-#endif
-#ifndef PB_WT_AUX
-#define PB_WT_AUX 19        // cache policy of the write-through form: 1 = sc0, 2 = nt, 16 = sc1 (sc0 sc1 = system scope)
 #endif
 // four consecutive channels c4 .. c4 + 3 of the row whose plane starts at `row` (wave-uniform)
 __device__ __forceinline__ void store_plane4(float *row, int c4, float a, float b, float c, float d)
@@ -368,15 +361,7 @@ __device__ __forceinline__ void store_plane4(float *row, int c4, float a, float 
     return;
 #endif
 #endif
-#if PB_NT_STORES == 2
-    // Written through to the fabric (system scope) without allocating in this die's L2: a reader on another die that
-    // learns from an atomic counter that the row is complete sees it without a cache write-back in between.  (A
-    // buffer store, not an asm block: the compiler must know about every vector-memory instruction -- on gfx9 stores
-    // and loads share vmcnt and stores complete out of order, so a store it cannot see breaks its s_waitcnt counts.)
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)row, 0, PB_NCHANOUT * 4, 0x00020000);
-    typedef unsigned u4s __attribute__((ext_vector_type(4)));
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4s, v), rs, c4 * 4, 0, PB_WT_AUX);
-#elif PB_NT_STORES
+#if PB_NT_STORES
     __builtin_nontemporal_store(v, (f4s *)(row + c4));
 #else
     *(f4s *)(row + c4) = v;

@@ -69,9 +69,6 @@ struct ChanArgs {
     float *wrow_out;
     uint32_t *rowmask_out;
     const DagConsts *dag;
-    // k_channelize_kur only: row-ready counters [A][S][R / chunk_rows] (nullptr: none), see pb_internal.h
-    unsigned *ready;
-    int chunk_rows, S;
 };
 
 // The row's 12500 bytes go to LDS through 16-byte loads (narrow per-lane loads are bound by the address unit,
@@ -443,14 +440,8 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
             const float inc = (float)PB_NKURTO / PB_NFFT;
             float w = 0.f;
             for (int k = PB_BLK_PER_FFT - __popc(m); k > 0; --k) w = w + inc;
-#if PB_FG
-            // (system-scope stores: detect may read the weight while this kernel is still running)
-            __hip_atomic_store(a.wrow_out + (size_t)ant * a.wrow_ant_stride + grow, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(a.rowmask_out + (size_t)ant * a.wrow_ant_stride + grow, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#else
             a.wrow_out[(size_t)ant * a.wrow_ant_stride + grow] = w;
             a.rowmask_out[(size_t)ant * a.wrow_ant_stride + grow] = m;
-#endif
             smw[0] = m;
             smw[1] = __builtin_bit_cast(unsigned, w);
         }
@@ -482,12 +473,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
         const bool second = a.rfi_mode == 1 || (a.rfi_mode == 2 && mask != 0);
         if (!second) continue;
         if (all_bad) {
-#if !PB_FG
             for (int c = tid; c < PB_NCHANOUT; c += 256) a.Pkur[prow + c] = __builtin_inff();
-#else
-            const float inf = __builtin_inff();
-            for (int c = tid * 4; c < PB_NCHANOUT; c += 1024) store_plane4(a.Pkur + prow, c, inf, inf, inf, inf);
-#endif
             if (a.rfi_mode == 1 && after_row >= 0) stage_request(a, tid, seg, after_row, 1, ant, st);
             continue;
         }
@@ -499,20 +485,6 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
         channelize_pass<1, true>(a, buf, tid, seg, row, pol, ant, st, mask, wrow, prow, after_row, 1,
                                  a.rfi_mode == 1 && pol == 0);
     }
-#if PB_FG     // (only the fine-grained build carries this: the extra live values cost k_channelize_kur twenty spilled registers)
-    if (a.ready) {
-        // This row is complete: every thread's plane stores (written through to the fabric, PB_NT_STORES 2) and wave
-        // 0's weight / mask have left for memory once vmcnt has drained; then one thread tells detect, which runs
-        // beside this kernel and takes a chunk of rows when its counter is full.
-#ifndef FG_NOWAIT          // (timing experiments: what the wait for the stores' acknowledgements costs; results invalid)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        __syncthreads();
-        if (threadIdx.x == 0)
-            __hip_atomic_fetch_add(a.ready + ((size_t)ant * a.S + seg) * (a.R / a.chunk_rows) + row / a.chunk_rows, 1u,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#endif
 #ifdef KUR_STAMP
     if (threadIdx.x == 0 && blockIdx.z == 0) {
         const unsigned wg = blockIdx.x + gridDim.x * blockIdx.y;
@@ -590,9 +562,6 @@ hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now)
     a.wrow_out = h->d_wrow;
     a.rowmask_out = pb_rowmask(h);
     a.dag = h->d_dag;
-    a.ready = pb_fine_grained(h) ? h->d_ready : nullptr;
-    a.chunk_rows = h->chunk_rows;
-    a.S = h->S;
     if (pb_fused_kurtosis(h)) {
         // one workgroup per row (both pols): it computes the row's flags itself
         dim3 gk((unsigned)h->R, (unsigned)nseg, (unsigned)h->A);

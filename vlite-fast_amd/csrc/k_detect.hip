@@ -104,7 +104,7 @@ hipError_t launch_copy_out(const PbSched &sched, uint8_t *host_pinned, const uin
     return hipGetLastError();
 }
 
-hipError_t launch_detect(pb_handle *h, int nseg, int, bool fine_grained)
+hipError_t launch_detect(pb_handle *h, int nseg, int)
 {
     if (h->cfg.fft_backend == PB_FFT_HIPFFT) {
         // complex spectra -> power planes of the segments just transformed (all antennas at once when
@@ -124,7 +124,7 @@ hipError_t launch_detect(pb_handle *h, int nseg, int, bool fine_grained)
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    return launch_detect_pow(h, nseg, fine_grained);
+    return launch_detect_pow(h, nseg);
 }
 
 // ---- incoherent coadd helpers (pb_coadd_local / pb_coadd_finish) ----

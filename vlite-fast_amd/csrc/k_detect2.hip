@@ -51,30 +51,10 @@ struct Detect2Args {
     size_t trim, ave_per_seg;
     int S, R, nseg;
     float scale, oms, tscale;
-    // Fine-grained coupling to the channeliser of the SAME batch, which is still running (pb_internal.h): chunk (seg,
-    // rb) of antenna ant may be read once ready[(ant * S + seg) * cps + rb] has reached target[seg]; nullptr: every
-    // row was complete before this kernel started.  fg_error: set when a workgroup gives up waiting.
-    const unsigned *ready;
-    unsigned target[PB_FG_MAXSEG];
-    unsigned *fg_error;
 };
 
-#ifndef D2_POLL_SLEEP
-#define D2_POLL_SLEEP 32           // x 64 cycles between two polls of a counter (256 workgroups poll the same word)
-#endif
-#ifndef D2_SPIN_LIMIT
-#define D2_SPIN_LIMIT (1 << 20)    // polls of a row-ready counter before a workgroup gives up (seconds: a lost producer)
-#endif
-
 #ifndef D2_LOAD_AUX
-// cache-policy bits of the plane loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).  The fine-grained build reads at system
-// scope: the planes may have been written (through, fft_lds.h) by a kernel that is still running on another die -- a
-// line this die's L2 kept from the buffer's previous use must not answer.  Costs nothing (profiles/r04_notes.md).
-#if PB_FG
-#define D2_LOAD_AUX 17
-#else
-#define D2_LOAD_AUX 0
-#endif
+#define D2_LOAD_AUX 0              // cache-policy bits of the plane loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
 #endif
 #ifndef D2_PRIO_A
 #define D2_PRIO_A 3                // wave priority of the recurrence wave
@@ -305,29 +285,6 @@ template <int DEPTH> struct Cursor {
 
 }  // namespace
 
-// the chunk's rows are complete (all lanes poll the same word; system-scope loads: never a stale line)
-__device__ __forceinline__ void wait_rows_ready(const Detect2Args &a, int ant, int seg, int rb, int cps)
-{
-    if (!a.ready) return;
-    const unsigned *p = a.ready + ((size_t)ant * a.S + seg) * cps + rb;
-    const unsigned tgt = a.target[seg < PB_FG_MAXSEG ? seg : 0];
-    int spins = 0;
-    while ((int)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - tgt) < 0) {
-        __builtin_amdgcn_s_sleep(D2_POLL_SLEEP);
-        if (++spins > D2_SPIN_LIMIT) {
-            if ((threadIdx.x & 63) == 0) __hip_atomic_store(a.fg_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;
-        }
-    }
-}
-
-__device__ __forceinline__ bool rows_ready_now(const Detect2Args &a, int ant, int seg, int rb, int cps)
-{
-    const unsigned *p = a.ready + ((size_t)ant * a.S + seg) * cps + rb;
-    const unsigned tgt = a.target[seg < PB_FG_MAXSEG ? seg : 0];
-    return (int)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - tgt) >= 0;
-}
-
 template <int T, bool KUR, int NPOL, int NBIT, int DEPTH>
 __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[T][64], float4 (*s_u)[T / 4][64],
                                              float (*s_u0)[64], float (*s_w)[T])
@@ -374,27 +331,20 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
             else if (n == 1) wait_vmcnt<LPC>();
             else wait_vmcnt<(DEPTH - 1) * LPC>();           // (DEPTH <= 3: n == 2)
         };
-        // Chunks are requested up to DEPTH ahead of the step that consumes them -- as far as their rows are known to be
-        // complete (fine-grained coupling: a chunk that is not is only waited for when the NEXT step needs it; the
-        // look-ahead never holds up chunks that have landed).  Without counters every chunk is complete: chunk
-        // k + DEPTH is requested in step k, as before.
+        // chunks are requested DEPTH ahead of the step that consumes them: chunk k + DEPTH in step k
         Cursor<DEPTH> cu;
         cu.init(0, cps);
-        auto fill = [&](int must, int upto) {       // request chunks < upto; block for those <= must
+        auto fill = [&](int upto) {       // request chunks < upto
             while (cu.c < nchunk && cu.c < upto) {
-                if (a.ready) {
-                    if (cu.c <= must) wait_rows_ready(a, ant, cu.seg, cu.rb, cps);
-                    else if (!rows_ready_now(a, ant, cu.seg, cu.rb, cps)) break;
-                }
                 issue(cu);
                 cu.next(cps);
             }
         };
-        fill(0, DEPTH);
+        fill(DEPTH);
         wait_chunks(cu.c - 1);                       // chunk 0 has landed
         step_barrier();
         for (int k = 0; k < nstep; ++k) {
-            fill(k + 1, k + 1 + DEPTH);
+            fill(k + 1 + DEPTH);
 #ifdef D2_STAMP
             const long long tw0 = D2_NOW();
 #endif
@@ -414,9 +364,7 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
         const float scale = a.scale, oms = a.oms;
         // row weights of the next chunk are requested one step ahead (rows of chunk k are the contiguous
         // wrow[k*T .. k*T+T-1]) and staged in LDS for phase B
-        // (system-scope loads of the weights: the channeliser that wrote them may still be running, see D2_LOAD_AUX;
-        //  the first chunk's only after the barrier behind which the loader has seen that chunk complete)
-        auto ldw = [&](size_t i) { return __hip_atomic_load(wrow + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+        auto ldw = [&](size_t i) { return wrow[i]; };
         Cursor<DEPTH> cu;
         cu.init(0, cps);
         step_barrier();
@@ -433,8 +381,7 @@ __device__ __forceinline__ void detect2_body(const Detect2Args &a, float (*s_p)[
                     // initialise the bandpass from this segment's mean (:406-411, :444-461): needs the WHOLE segment
                     const float *p = inA + (size_t)cu.seg * seg_stride;
                     const size_t wseg = (size_t)cu.seg * R;
-                    for (int c = 0; c < cps; ++c) wait_rows_ready(a, ant, cu.seg, c, cps);
-                    auto ldp = [&](int t) { return __hip_atomic_load(p + (size_t)t * PB_NCHANOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+                    auto ldp = [&](int t) { return p[(size_t)t * PB_NCHANOUT]; };
                     if (!KUR) {
                         for (int t = 0; t < R; ++t) bp += ldp(t);
                         bp /= (float)R;
@@ -650,7 +597,7 @@ static void launch_all(const Detect2Args &a, int mode, int npol, int nbit, dim3 
     }
 }
 
-hipError_t launch_detect_pow(pb_handle *h, int nseg, bool fine_grained)
+hipError_t launch_detect_pow(pb_handle *h, int nseg)
 {
     Detect2Args a;
     a.P[0] = h->d_Praw;
@@ -670,13 +617,6 @@ hipError_t launch_detect_pow(pb_handle *h, int nseg, bool fine_grained)
     a.scale = (float)(tsamp / 1.0);
     a.oms = 1 - a.scale;
     a.tscale = (float)sqrt(1. / PB_NSCRUNCH);
-    a.ready = nullptr;
-    a.fg_error = h->d_fg_error;
-    for (int i = 0; i < PB_FG_MAXSEG; ++i) a.target[i] = 0;
-    if (fine_grained) {
-        a.ready = h->d_ready;
-        for (int i = 0; i < nseg && i < PB_FG_MAXSEG; ++i) a.target[i] = (unsigned)h->chunk_rows * h->ready_epoch[h->cur_set][i];
-    }
     dim3 grid(PB_NCHANOUT / 32, h->cfg.rfi_mode == 2 ? 2 : 1, h->A);
     // three chunks in flight where detect runs wholly beside the next batch's channeliser (it flags its own rows and
     // starts straight behind the previous one), two otherwise (measured both ways, see the comment on DEPTH)

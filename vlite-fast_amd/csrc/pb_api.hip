@@ -65,12 +65,18 @@ PbSched pb_read_sched()
     PbSched s;
     s.overlap_detect = env_int("PB_OVERLAP_DETECT", 1);
     s.kur_early = env_int("PB_KUR_EARLY", 1);
-    s.fine_grained = env_int("PB_FINE_GRAINED", 1);
     s.detect_depth = env_int("PB_DETECT_DEPTH", 0);
+    // switches that only ever served one timing experiment each are read by the experiments build alone
+    s.copy_dma = 0;
+    s.copy_wgs = 8;
+    s.det_cus = 0;
+    s.det_prio = 1;
+#if PB_EXPERIMENTS
     s.copy_dma = env_int("PB_COPY_DMA", 0);
     s.copy_wgs = env_int("PB_COPY_WGS", 8);
     s.det_cus = env_int("PB_DET_CUS", 0);
     s.det_prio = env_int("PB_DET_PRIO", 1);
+#endif
     return s;
 }
 
@@ -82,17 +88,6 @@ bool pb_fused_kurtosis(const pb_handle *h)
     // (tools/experiments/k_channelize_pfb_kur.patch).
     if (h->fuse < 1 || h->cfg.taps != 1) return false;
     return h->cfg.fft_backend == PB_FFT_LDS && h->cfg.rfi_mode != 0 && !h->cfg.debug_keep;
-}
-
-bool pb_fine_grained(const pb_handle *h)
-{
-    // Only in the PB_FG build (libpb_hip_fg.so): bit-exact (the pipelined parity tests pass with it), but measured
-    // slower -- 0.647 - 0.655 against 0.632 ms per step in 40-step regions on the same box (profiles/r04_notes.md):
-    // detect's workgroups of batch k + 1 can only start when batch k's have all left, by then the channeliser has taken
-    // their places, and a detect that trickles in over 0.3 ms no longer has a step's slack to finish in.
-    const int allow = PB_FG && h->sched.fine_grained;
-    return allow && h->sched.overlap_detect && pb_fused_kurtosis(h) && h->cfg.taps == 1 && h->sets.size() >= 2 && h->A == 1 && h->S <= PB_FG_MAXSEG &&
-           h->d_ready != nullptr;
 }
 
 extern "C" void *pb_host_alloc(size_t nbytes)
@@ -280,7 +275,6 @@ static void store_set(pb_handle *h, int i)
     b.d_wrow = h->d_wrow; b.d_stats = h->d_stats; b.d_fraw = h->d_fraw; b.d_fkur = h->d_fkur;
     b.d_Praw = h->d_Praw; b.d_Pkur = h->d_Pkur; b.d_ave = h->d_ave; b.d_Xraw = h->d_Xraw; b.d_Xkur = h->d_Xkur;
     b.d_coadd_target = h->d_coadd_target;
-    b.d_ready = h->d_ready;
     b.ev_chan = h->ev_chan; b.ev_det = h->ev_det; b.ev_cl = h->ev_cl; b.processed = h->processed;
 }
 
@@ -291,7 +285,6 @@ static void load_set(pb_handle *h, int i)
     h->d_wrow = b.d_wrow; h->d_stats = b.d_stats; h->d_fraw = b.d_fraw; h->d_fkur = b.d_fkur;
     h->d_Praw = b.d_Praw; h->d_Pkur = b.d_Pkur; h->d_ave = b.d_ave; h->d_Xraw = b.d_Xraw; h->d_Xkur = b.d_Xkur;
     h->d_coadd_target = b.d_coadd_target;
-    h->d_ready = b.d_ready;
     h->ev_chan = b.ev_chan; h->ev_det = b.ev_det; h->ev_cl = b.ev_cl; h->processed = b.processed;
     h->cur_set = i;
 }
@@ -350,21 +343,11 @@ static int create_impl(pb_handle *h)
     // One buffer set per pipeline slot (cfg.nsets): while detect + D2H of one batch run on the
     // second stream, kurtosis + channeliser of the next batch fill the other set.
     h->sets.resize(c.nsets);
-    h->chunk_rows = (R % 32 == 0) ? 32 : 8;
-    h->ready_epoch.assign(c.nsets, std::vector<uint32_t>(S, 0u));
-    {
-        // (mapped page-locked word: the device writes it only when a detect workgroup gives up waiting for a row)
-        HIPCHK(h, hipHostMalloc((void **)&h->d_fg_error, sizeof(uint32_t), hipHostMallocMapped));
-        *h->d_fg_error = 0;
-    }
     for (int si = 0; si < c.nsets; ++si) {
     h->d_in = h->d_flags = h->d_codes = h->h_codes = nullptr;
     h->d_wrow = h->d_stats = h->d_fraw = h->d_fkur = h->d_Praw = h->d_Pkur = h->d_ave = nullptr;
     h->d_Xraw = h->d_Xkur = nullptr;
     h->d_coadd_target = nullptr;
-    h->d_ready = nullptr;
-    HIPCHK(h, dmalloc(h, &h->d_ready, A * S * (R / h->chunk_rows)));
-    HIPCHK(h, hipMemset(h->d_ready, 0, A * S * (R / h->chunk_rows) * sizeof(uint32_t)));
     HIPCHK(h, dmalloc(h, &h->d_in, in_elems + 64));   // + overhang of the channeliser's 16-byte row loads
     HIPCHK(h, dmalloc(h, &h->d_flags, A * S * h->nblk_seg));
     HIPCHK(h, hipMemset(h->d_flags, 0, A * S * h->nblk_seg));
@@ -529,9 +512,6 @@ extern "C" int pb_create(const pb_config *cfg, pb_handle **out)
     h->last_set = -1;
     h->staged = false;
     h->d_coadd_target = nullptr;
-    h->d_ready = nullptr;
-    h->d_fg_error = nullptr;
-    h->chunk_rows = 32;
     h->d_coadd_codes = h->h_coadd_codes = nullptr;
     h->ev_coadd[0] = h->ev_coadd[1] = nullptr;
     h->coadd_slot = h->coadd_last = 0;
@@ -560,7 +540,7 @@ extern "C" void pb_destroy(pb_handle *h)
     for (auto &b : h->sets) {
         if (b.d_in == h->d_in) stored = true;
         void *sp[] = {b.d_in, b.d_flags, b.d_codes, b.d_wrow, b.d_stats, b.d_fraw, b.d_fkur,
-                      b.d_Praw, b.d_Pkur, b.d_ave, b.d_Xraw, b.d_Xkur, b.d_ready};
+                      b.d_Praw, b.d_Pkur, b.d_ave, b.d_Xraw, b.d_Xkur};
         for (void *p : sp)
             if (p) (void)hipFree(p);
         if (b.h_codes) (void)hipHostFree(b.h_codes);
@@ -570,7 +550,7 @@ extern "C" void pb_destroy(pb_handle *h)
     }
     if (!stored) {  // pb_create failed half-way through a set: free the loose members
         void *sp[] = {h->d_in, h->d_flags, h->d_codes, h->d_wrow, h->d_stats, h->d_fraw, h->d_fkur,
-                      h->d_Praw, h->d_Pkur, h->d_ave, h->d_Xraw, h->d_Xkur, h->d_ready};
+                      h->d_Praw, h->d_Pkur, h->d_ave, h->d_Xraw, h->d_Xkur};
         for (void *p : sp)
             if (p) (void)hipFree(p);
         if (h->h_codes) (void)hipHostFree(h->h_codes);
@@ -584,7 +564,6 @@ extern "C" void pb_destroy(pb_handle *h)
         if (h->h_frame_idx[i]) (void)hipHostFree(h->h_frame_idx[i]);
         if (h->ev_idx[i]) (void)hipEventDestroy(h->ev_idx[i]);
     }
-    if (h->d_fg_error) (void)hipHostFree(h->d_fg_error);
     if (h->d_coadd_codes) (void)hipFree(h->d_coadd_codes);
     if (h->h_coadd_codes) (void)hipHostFree(h->h_coadd_codes);
     for (int i = 0; i < 2; ++i)
@@ -1039,12 +1018,6 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
         }
         HIPCHK(h, e);
     }
-    // Row-ready counters: this batch brings every segment slot it uses one epoch further (the channeliser adds one per
-    // finished row, detect waits for chunk_rows x epoch).  Booked before either kernel is queued.
-    // (PB_FINE_GRAINED=2, timing experiments: the channeliser signals its rows, detect still waits for the event)
-    const bool fine = pb_fine_grained(h) && (int)h->sets.size() >= 2 && h->sched.fine_grained != 2;
-    if (fine)
-        for (int i = 0; i < nseg; ++i) h->ready_epoch[h->cur_set][i] += 1;
     if (hipfft) {
         StageTimer t(h, PB_ST_FFT);
         int rc = exec_fft(h, nseg);
@@ -1071,17 +1044,13 @@ extern "C" int pb_process(pb_handle *h, int nseg, int inject_now)
     // it off).  With one buffer set everything stays on one stream.
     if (h->sched.overlap_detect && h->sets.size() >= 2 && !hipfft) {
         hipStream_t s_main = h->stream;
-        // Fine-grained: detect of THIS batch starts beside its channeliser and follows it chunk by chunk (row-ready
-        // counters), so it does not wait for the channeliser's end: a batch's filterbank bytes are complete shortly
-        // after its channeliser, not a step later, and a run's last detect no longer has the machine to itself.
-        // (It still follows the previous detect in its stream, and by then every earlier channeliser has finished.)
-        hipError_t e2 = fine ? hipSuccess : hipStreamWaitEvent(h->s_det, h->ev_fftdone, 0);
+        hipError_t e2 = hipStreamWaitEvent(h->s_det, h->ev_fftdone, 0);
         if (e2 == hipSuccess) e2 = hipStreamWaitEvent(h->s_det, h->ev_det, 0);  // this set's previous bytes have left
         if (e2 == hipSuccess) e2 = hipStreamWaitEvent(h->s_det, h->ev_cl, 0);   // planes of this set were summed
         h->stream = h->s_det;
         if (e2 == hipSuccess) {
             StageTimer t(h, PB_ST_DETECT);
-            if (!(pb_skip_mask() & 2)) e2 = launch_detect(h, nseg, inject_now, fine);
+            if (!(pb_skip_mask() & 2)) e2 = launch_detect(h, nseg, inject_now);
             t.stop();
         }
         if (e2 == hipSuccess) e2 = hipEventRecord(h->ev_chan, h->s_det);   // this set's kernels are done
@@ -1144,16 +1113,6 @@ extern "C" int pb_select_set(pb_handle *h, int set)
     return PB_OK;
 }
 
-// The fine-grained build's detect gives up (and says so in this mapped word) when a row it waits for never comes.
-// Fail-stop, like the reference's cudacheck (src/cuda_util.cu:4-12): the word is never cleared, every later call
-// that hands out results of this handle -- bytes, planes, device addresses, the coadd leg -- fails.
-static int check_fine_grained(pb_handle *h)
-{
-    if (h->d_fg_error && *(volatile uint32_t *)h->d_fg_error)
-        return fail(h, PB_ESTATE, "a detect workgroup gave up waiting for the channeliser's rows (row-ready counters of the fine-grained build): results invalid");
-    return PB_OK;
-}
-
 extern "C" int pb_fetch_ptr(pb_handle *h, int ant, int stream, const uint8_t **codes)
 {
     if (!h || !codes) return PB_EINVAL;
@@ -1161,7 +1120,6 @@ extern "C" int pb_fetch_ptr(pb_handle *h, int ant, int stream, const uint8_t **c
     if (stream < 0 || stream > 1) return fail(h, PB_EINVAL, "stream must be 0 or 1");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipEventSynchronize(h->ev_det));
-    if (int rc = check_fine_grained(h)) return rc;
     *codes = h->h_codes + ((size_t)ant * 2 + stream) * h->S * h->trim;
     return PB_OK;
 }
@@ -1177,7 +1135,6 @@ extern "C" int pb_fetch(pb_handle *h, int ant, int seg0, int nseg, uint8_t *raw_
     // the selected set's detect + asynchronous D2H (pinned mirror h_codes) have an event of
     // their own, so fetching one set does not wait for work in flight on the other
     HIPCHK(h, hipEventSynchronize(h->ev_det));
-    if (int rc = check_fine_grained(h)) return rc;
     const size_t S = h->S;
     const uint8_t *c0 = h->h_codes + (((size_t)ant * 2 + 0) * S + seg0) * h->trim;
     const uint8_t *c1 = h->h_codes + (((size_t)ant * 2 + 1) * S + seg0) * h->trim;
@@ -1212,7 +1169,6 @@ extern "C" int pb_output_dev(pb_handle *h, int ant, int stream, void **codes, vo
     if (!h) return PB_EINVAL;
     if (check_ant(h, ant)) return PB_EINVAL;
     if (stream < 0 || stream > 1) return fail(h, PB_EINVAL, "stream must be 0 or 1");
-    if (int rc = check_fine_grained(h)) return rc;
     if (codes) *codes = h->d_codes + ((size_t)ant * 2 + stream) * h->S * h->trim;
     if (ave) {
         *ave = h->d_ave ? h->d_ave + ((size_t)ant * 2 + stream) * h->S * h->ave_per_seg : nullptr;
@@ -1235,7 +1191,6 @@ extern "C" int pb_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumula
     if (!h || !d_sum) return PB_EINVAL;
     if (!h->cfg.keep_ave) return fail(h, PB_ESTATE, "pb_coadd_local needs keep_ave=1");
     if (nseg < 1 || nseg > h->S) return fail(h, PB_EINVAL, "pb_coadd_local: nseg out of range");
-    if (int rc = check_fine_grained(h)) return rc;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     // The fp32 planes come from this set's detect, which may have run on the second stream.  On a
     // coadd stream of its own (pb_set_coadd_stream) this wait holds up neither the next batch's
@@ -1273,7 +1228,6 @@ extern "C" int pb_coadd_local_codes(pb_handle *h, int nseg, float *d_sum, int ac
     if (!h || !d_sum) return PB_EINVAL;
     if (nseg < 1 || nseg > h->S) return fail(h, PB_EINVAL, "pb_coadd_local_codes: nseg out of range");
     if (nseg > h->processed) return fail(h, PB_EINVAL, "pb_coadd_local_codes: more segments than the batch holds");
-    if (int rc = check_fine_grained(h)) return rc;
     if (h->d_coadd_target && d_sum == h->d_coadd_target)
         return fail(h, PB_ESTATE, "pb_coadd_local_codes: d_sum is the set's fp32 coadd target");
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1317,7 +1271,6 @@ extern "C" int pb_coadd_local_tree(pb_handle *h, int nseg, const int32_t *ant_or
     if (!h->cfg.keep_ave) return fail(h, PB_ESTATE, "pb_coadd_local_tree needs keep_ave=1");
     if (nseg < 1 || nseg > h->S) return fail(h, PB_EINVAL, "pb_coadd_local_tree: nseg out of range");
     if (nseg > h->processed) return fail(h, PB_EINVAL, "pb_coadd_local_tree: more segments than the batch holds");
-    if (int rc = check_fine_grained(h)) return rc;
     if (n < 1 || n > PB_COADD_MAX_LEAVES) return fail(h, PB_EINVAL, "pb_coadd_local_tree: 1..PB_COADD_MAX_LEAVES leaves");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int stream = h->cfg.rfi_mode == 0 ? 0 : 1;

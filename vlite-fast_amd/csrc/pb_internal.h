@@ -34,7 +34,7 @@ struct FrbParams {
 // twiddle tables of the LDS FFT (all float2, built on the host in double); the radix-5/25/10 twiddles
 // are compile-time literals (fft_consts.h)
 struct FftTables {
-    float2 *tw2;    // [25 k][24 r]   pass-2 twiddles exp(-2 pi i r k / 625), r = 1..24
+    float2 *tw2;    // [12 pairs (r, r+1)][25 k][2]   pass-2 twiddles exp(-2 pi i r k / 625), r = 1..24 (fft_lds.h: load_t2)
     float2 *tw3;    // [625 j][10]    pass-3 twiddles exp(-2 pi i r j / 6250), r = 1..9, one pad
     float2 *post;   // [6251]
     float2 *postc;  // [4096] = post[2155..6250], its own 16-byte aligned allocation
@@ -48,11 +48,11 @@ struct FftTables {
 struct PbSched {
     int overlap_detect;   // PB_OVERLAP_DETECT (1): detect + copy-out on streams of their own beside the next batch
     int kur_early;        // PB_KUR_EARLY (1): >= 3 sets: the kurtosis pass does not wait for the previous channeliser
-    int fine_grained;     // PB_FINE_GRAINED (1; only in the PB_FG build): 0 off, 1 on, 2 signal rows but wait for the event
     int detect_depth;     // PB_DETECT_DEPTH (0 = by configuration): 2 / 3 chunks in flight in detect's ring
+    // read from the environment by the experiments build only (`make exp`); the shipped library uses the defaults
     int copy_dma;         // PB_COPY_DMA (0): 1 = hipMemcpyAsync instead of the copy-out kernel
     int copy_wgs;         // PB_COPY_WGS (8): workgroups of the copy-out kernel
-    int det_cus;          // PB_DET_CUS (0): CU mask of the detect stream (timing experiments)
+    int det_cus;          // PB_DET_CUS (0): CU mask of the detect stream
     int det_prio;         // PB_DET_PRIO (1): detect's stream at the highest priority
 };
 PbSched pb_read_sched();
@@ -97,11 +97,6 @@ struct pb_handle {
     float frb_width, frb_amp;   // inject_frb parameters (rows, amplitude factor)
     // --- pipeline slots: the d_* buffers above (except d_bp, d_vdif, tables) exist once per
     // set; the members above always alias the SELECTED set (pb_select_set)
-    // Row-ready counters of the selected set: [A][S][R / chunk_rows] uint32, one per detect chunk.  The channeliser
-    // that flags its own rows adds 1 per finished row (both pols, both planes written through to the fabric); detect,
-    // launched beside that channeliser instead of after it, takes a chunk only once its counter has reached
-    // chunk_rows x (number of batches the set's segment has seen): pb_handle::ready_epoch.  Monotonic: never reset.
-    uint32_t *d_ready;
     uint8_t *h_codes;      // pinned mirror of d_codes, filled asynchronously after detect
     hipEvent_t ev_chan;    // kernels of this set done (its D2H may start)
     hipEvent_t ev_det;     // D2H of this set done (set may be refilled / fetched)
@@ -111,14 +106,10 @@ struct pb_handle {
         uint8_t *d_in, *d_flags, *d_codes, *h_codes;
         float *d_wrow, *d_stats, *d_fraw, *d_fkur, *d_Praw, *d_Pkur, *d_ave, *d_coadd_target;
         float2 *d_Xraw, *d_Xkur;
-        uint32_t *d_ready;
         hipEvent_t ev_chan, ev_det, ev_cl;
         int processed;
     };
-    std::vector<std::vector<uint32_t>> ready_epoch;   // [set][seg] batches that segment slot of the set has seen
-    int chunk_rows;                                    // detect's chunk: 32 rows, 8 when R is not a multiple of 32
     int fuse;                                          // PB_FUSE_KURTOSIS at pb_create (pb_fused_kurtosis)
-    uint32_t *d_fg_error;                              // a detect workgroup gave up waiting for a row (must stay 0)
     std::vector<BufSet> sets;
     int cur_set;
     hipStream_t s_det;     // detect of the previous batch (pipelined mode); copy-out in the single-set mode
@@ -150,24 +141,11 @@ struct pb_handle {
 // front of it: in-library FFT, rectangular window, an RFI mode that flags, no statistics kept.  PB_FUSE_KURTOSIS=0
 // keeps the two kernels (timing experiments).
 bool pb_fused_kurtosis(const pb_handle *h);
-// PB_FG: the library is built WITH the fine-grained coupling below (libpb_hip_fg.so, `make fg`): plane stores written
-// through to the fabric and detect's loads at system scope, which the ordinary build does not pay for (the written-
-// through stores show as +9 % HBM write traffic in the PMC counters; the step does not change).
-#ifndef PB_FG
-#define PB_FG 0
-#endif
 // PB_EXPERIMENTS: the experiments build (libpb_hip_exp.so, `make exp`) also reads PB_SKIP, which leaves kernels out
 // (results invalid; energy and upper-bound measurements).  Never in the shipped library.
 #ifndef PB_EXPERIMENTS
 #define PB_EXPERIMENTS 0
 #endif
-// detect runs beside the channeliser of its OWN batch, chunk by chunk behind it (row-ready counters), instead of
-// after it: the fused in-library-FFT path with two or more buffer sets, one antenna per handle, at most 16 segments
-// per call.  An experiment that is bit-exact but did not pay (profiles/r04_notes.md): only in the PB_FG build, where
-// PB_FINE_GRAINED=0 switches back to the event between the two kernels.
-bool pb_fine_grained(const pb_handle *h);
-#define PB_FG_MAXSEG 16
-
 // row flag masks (bit r = kurtosis block r of the row is flagged), written by k_kurtosis_row behind the weights
 static inline uint32_t *pb_rowmask(pb_handle *h) { return (uint32_t *)(h->d_wrow + (size_t)h->A * h->S * h->R); }
 
@@ -177,14 +155,14 @@ hipError_t launch_deframe(pb_handle *h, int ant, int seg0, size_t nframes_per_th
 hipError_t launch_dag_scan(pb_handle *h, const DagConsts &c, uint32_t bits0, int n, uint8_t *d_out);
 hipError_t launch_dag_check(pb_handle *h, uint32_t bits_lo, uint64_t n, unsigned long long *d_mismatches);
 hipError_t launch_inject_c64(pb_handle *h, int nseg, int inject_now);
-hipError_t launch_detect(pb_handle *h, int nseg, int inject_now, bool fine_grained = false);
-hipError_t launch_detect_pow(pb_handle *h, int nseg, bool fine_grained = false);
+hipError_t launch_detect(pb_handle *h, int nseg, int inject_now);
+hipError_t launch_detect_pow(pb_handle *h, int nseg);
 // device -> pinned host copy done by a kernel (see k_detect.hip: hipMemcpyAsync blocks the host now and then)
 hipError_t launch_copy_out(const PbSched &sched, uint8_t *host_pinned, const uint8_t *dev, size_t nbytes, hipStream_t st);
 hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now);
 hipError_t launch_pfb_weights(pb_handle *h, int nseg);
-hipError_t launch_pfb_history(pb_handle *h, int nseg);   // taps = 4: behind the weights, into the history slot the batch does not read
+hipError_t launch_pfb_history(pb_handle *h, int nseg);   // taps = 4: the batch's last three rows and flags into the history slot the NEXT batch reads
 hipError_t launch_channelize_f32(pb_handle *h, const float *d_x, int nrows, int taps, float2 *d_out);
 hipError_t launch_coadd_local(pb_handle *h, int nseg, float *d_sum, int accumulate, hipStream_t st);
 hipError_t launch_coadd_digitise_flat(pb_handle *h, const float *d_sum, size_t nfloat, float scale, uint8_t *d_codes,
