@@ -40,6 +40,7 @@ sys.path.insert(0, ROOT)
 
 NFFT, NCHANOUT, ROWS = 12500, 4096, 1024
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+SURVEY_UNFUSED_BYTES_PER_SEGMENT = 845_900_000      # SURVEY.md section 8(d), RFI mode 2: the reference's unfused kernel chain
 
 
 def kernel_source_hash():
@@ -277,30 +278,68 @@ def valu_record(args, taps, ms_per_step, gfx_mhz):
             "frac": round(cyc / N_SIMD / step_cycles, 4), "source": mv["source"]}
 
 
+def _parse_corun(text):
+    """rows of tools/corun_probe.py's output: {(PB_SKIP, co-runner): [(channelize ms per launch, W, J per step)]}, and
+    the kernel-source hashes its header lines carry"""
+    rows, skip, shas = {}, None, set()
+    for line in text.splitlines():
+        if line.startswith("PB_SKIP="):
+            skip = line.split()[0].split("=")[1]
+            m = re.search(r"kernel_source_sha16=([0-9a-f]+)", line)
+            shas.add(m.group(1) if m else None)
+        m = re.match(r"^(\S.*?)\s+step ([0-9.]+) ms\s+channelize ([0-9.]+) ms/launch\s+detect ([0-9.]+)\s+([0-9.]+) W\s+([0-9.]+) J/step", line)
+        if m:
+            rows.setdefault((skip, m.group(1).strip()), []).append((float(m.group(3)), float(m.group(5)), float(m.group(6))))
+    return rows, shas
+
+
 def residency_record():
-    """What bounds the step, from the committed co-runner decomposition (tools/corun_probe.py, profiles/r05_notes.md
-    section 1): the channeliser's per-launch time alone, beside 256 SLEEPING workgroups that only hold the 57 KB of LDS
-    a detect workgroup takes (one per CU), and beside the real detect, with the socket power of each.  Not measured by
-    this run (the probe needs the experiments build): the figures and their source file are quoted."""
-    path = os.path.join(ROOT, "profiles", "r05_corun_probe.txt")
+    """What bounds the step: the channeliser's per-launch time alone, beside 256 SLEEPING workgroups that only hold the
+    57 KB of LDS a detect workgroup takes (one per CU), and beside the real detect, with the socket power of each
+    (tools/corun_probe.py + tools/corun.hip, profiles/r05_notes.md section 1).  MEASURED by this run when the experiments
+    build is in the tree and at least as new as the kernel sources (`make -C vlite-fast_amd/csrc exp` +
+    build/libcorun.so: the probe needs detect's launch left out, which the shipped library cannot do) -- the probe then
+    runs as a child process for about a second of GPU time; otherwise QUOTED from the newest committed record taken
+    with these kernel sources (hash check, like `traffic` and `valu`); None when neither exists."""
+    import glob
+    import subprocess
+    sha = kernel_source_hash()
+    csrc = os.path.join(ROOT, "vlite-fast_amd", "csrc")
+    exp, corun = os.path.join(csrc, "libpb_hip_exp.so"), os.path.join(ROOT, "build", "libcorun.so")
+    text, source, measured = None, None, False
     try:
-        rows = {}
-        skip = None
-        for line in open(path):
-            if line.startswith("PB_SKIP="):
-                skip = line.split()[0].split("=")[1]
-            m = re.match(r"^(\S.*?)\s+step ([0-9.]+) ms\s+channelize ([0-9.]+) ms/launch\s+detect ([0-9.]+)\s+([0-9.]+) W\s+([0-9.]+) J/step", line)
-            if m:
-                rows.setdefault((skip, m.group(1).strip()), []).append((float(m.group(3)), float(m.group(5)), float(m.group(6))))
+        srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
+        if os.path.exists(exp) and os.path.exists(corun) and os.path.getmtime(exp) >= max(os.path.getmtime(f) for f in srcs):
+            out = []
+            for skip, kinds in (("2", ["none", "hold,256,384,58368"]), ("0", ["none"])):
+                env = dict(os.environ, PB_LIBPATH=exp, PB_SKIP=skip, CORUN_MS="150")
+                p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "corun_probe.py")] + kinds, env=env,
+                                   capture_output=True, text=True, timeout=180)
+                if p.returncode != 0:
+                    raise RuntimeError("corun_probe: " + p.stderr[-300:])
+                out.append(p.stdout)
+            text, source, measured = "\n".join(out), "measured by this run: tools/corun_probe.py on the experiments build", True
+    except Exception as e:
+        text, source = None, "in-run probe failed: %s" % repr(e)[:200]
+    if text is None:
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_corun_probe*.txt")), reverse=True):
+            t = open(f).read()
+            if _parse_corun(t)[1] == {sha}:
+                text, source = t, "profiles/%s (quoted: taken with these kernel sources, not re-measured by this run)" % os.path.basename(f)
+                break
+    if text is None:
+        return None
+    try:
+        rows, _ = _parse_corun(text)
         alone = rows[("2", "none")][-1]
         held = rows[("2", "hold 256 384 58368")][-1]
         pipe = rows[("0", "none")][-1]
         return {"channelize_ms_per_launch": {"alone": alone[0], "beside_256_sleeping_57KB_workgroups": held[0], "beside_detect": pipe[0]},
                 "socket_w": {"alone": alone[1], "beside_256_sleeping_57KB_workgroups": held[1], "beside_detect": pipe[1]},
+                "measured_in_run": measured, "kernel_source_sha16": sha,
                 "bound": "residency: three channeliser workgroups use 504 of 512 VGPRs per SIMD lane and 150 of 160 KB of LDS; a "
-                         "detect workgroup per CU takes the place of one (x 1.35 - 1.4), at a socket power 300 W below the cap",
-                "source": "profiles/r05_corun_probe.txt (tools/corun_probe.py + tools/corun.hip, experiments build; quoted, not "
-                          "re-measured by this run)"}
+                         "detect workgroup per CU takes the place of one, at a socket power well below the cap",
+                "source": source}
     except Exception as e:
         return {"error": repr(e)[:200]}
 
@@ -604,6 +643,18 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
         res["roofline"]["pipeline"] = {"algorithmic_bytes_per_step": step_bytes,
                                        "achieved": round(step_bytes / (dt / steps) / 1e9, 1),
                                        "frac": round(step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}
+        # SURVEY.md 8(d)'s traffic model of the reference's UNFUSED kernel chain (17 kernels + cuFFT, every intermediate
+        # through HBM): 845.9 MB per antenna-segment in RFI mode 2.  north_star's ">= 60 % HBM roofline" was written
+        # against that model; read at this run's samples per second it asks for more than the peak, i.e. the fused
+        # design does not move those bytes -- both readings are in the line.
+        if args.rfi_mode == 2 and args.backend == "lds":
+            sm = SURVEY_UNFUSED_BYTES_PER_SEGMENT * S * A
+            res["roofline"]["survey_model"] = {"bytes_per_antenna_segment": SURVEY_UNFUSED_BYTES_PER_SEGMENT, "bytes_per_step": sm,
+                                               "implied": round(sm / (dt / steps) / 1e9, 1), "unit": "GB/s",
+                                               "frac": round(sm / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4),
+                                               "note": "SURVEY 8(d): HBM bytes the reference's unfused chain moves per antenna-segment "
+                                                       "x this run's rate; frac > 1 means the fused kernels do not move those bytes "
+                                                       "(they move algorithmic_bytes_per_step), not that the peak was exceeded"}
     if leg is not None:
         leg.close()
     h.close()
@@ -689,7 +740,9 @@ def build_parser():
     ap.add_argument("--nsets", type=int, default=3,
                     help="buffer sets (1 = no batch pipelining; 3 = the host collects batch k - 2 after queuing batch "
                          "k, so that its wait for a copy-out never keeps the next batch from being queued)")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal)")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="nccl (= RCCL, default); rehearsals: gloo (one process per rank) or threads (the ranks as threads "
+                         "of this process, with --share-gpus: for boxes that allow few processes on a card)")
     ap.add_argument("--coadd-order", choices=["tree", "fast"], default="tree",
                     help="N > 1: tree (default) = the defined order of the fp32 additions (local tree, gather to rank 0, "
                          "root tree: the same coadded bytes on any number of GPUs); fast = one RCCL reduce(SUM)")
@@ -767,6 +820,8 @@ def main():
     args = build_parser().parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.dist_backend == "threads" and args.gpus > 1:
+        sys.exit(threaded_main(args))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args, argv))
 
@@ -802,6 +857,36 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)          # gloo: CPU rehearsal of the N > 1 path
 
+    rank_body(args, rank, world, local, cpu, torch, dist, dev, ndev)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def threaded_main(args):
+    """`--gpus N --dist-backend threads --share-gpus`: the N ranks as threads of THIS process on the one card
+    (vlite-fast_amd/threaded_ranks.py) -- the rehearsal of the N > 1 path (sharding, the coadd leg's indexing over N
+    slices, the configs3 sub-record at N = 8) for boxes that allow fewer processes on a GPU than N.  Times mean nothing."""
+    if not args.share_gpus:
+        raise SystemExit("bench.py: --dist-backend threads puts every rank on one card: a rehearsal, say --share-gpus")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < 1 or not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    tr = importlib.import_module("vlite-fast_amd.threaded_ranks")
+    dev = torch.device("cuda", 0)
+
+    def body(rank, world, dist):
+        torch.cuda.set_device(0)
+        rank_body(args, rank, world, 0, None, torch, dist, dev, ndev)
+        return 0
+
+    tr.run_as_threads(args.gpus, body)
+    return 0
+
+
+def rank_body(args, rank, world, local, cpu, torch, dist, dev, ndev):
+    """what one rank measures and (rank 0) prints, inside an initialised process group when world > 1"""
     lp = importlib.import_module("vlite-fast_amd.libpb")
     S, A = args.seg_per_step, args.ant_per_gpu
     if args.coadd_selftest and world == 1:
@@ -930,8 +1015,6 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 def ing_frames(S):

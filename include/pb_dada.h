@@ -17,8 +17,9 @@
  *   header write   :172-199, :981-989  dada_hdu_lock_write, ipcbuf_get_next_write, ipcbuf_mark_filled (4096)
  *   data write     :1416-1422 (coadd ring, one segment), :1482-1494 (10 s, then 1 s)  ipcio_write
  *   end of obs     :1498-1511 dada_hdu_unlock_write
- * tests/mock_dada/pb_dada_mock.c exports the same symbols over an in-memory ring (test infrastructure)
- * so that the binding and its call order are exercised without psrdada.
+ * Where psrdada is absent the tests compile the real shim (vlite-fast_amd/csrc/pb_dada_shim.c) against
+ * tests/mock_psrdada -- declarations of exactly the psrdada calls above and shared-file rings behind them (test
+ * infrastructure: it sits UNDER the shim and pins nothing about psrdada's ABI).
  */
 #ifndef PB_DADA_H
 #define PB_DADA_H

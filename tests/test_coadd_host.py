@@ -152,16 +152,17 @@ def _stream(ant):
     return hdr, body
 
 
-def _worker(rank, world, port, tmp, NANT, order, layout="auto"):
+def _worker(rank, world, port, tmp, NANT, order, layout="auto", transport="gloo", dist=None):
     import torch
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if transport == "gloo":
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     vdif, sigproc, dada, coadd, host = _mods()
     args = host.build_parser().parse_args(["--replay"] + ["unused"] * NANT + ["-b", "8", "-r", "2", "-w", "2", "--datadir", tmp,
                                            "--logdir", os.path.join(tmp, "logs"), "--rows-per-seg", str(R),
-                                           "--dist-backend", "gloo", "--coadd-order", order, "--coadd-layout", layout,
+                                           "--dist-backend", transport, "--coadd-order", order, "--coadd-layout", layout,
                                            "--out-sink", os.path.join(tmp, "co_ring.bin")])
     mine = coadd.antennas_of_rank(NANT, rank, world)
     rings = {}
@@ -173,21 +174,30 @@ def _worker(rank, world, port, tmp, NANT, order, layout="auto"):
         r.end_of_data()
         rings[a] = r
     h = FakeCoaddHandle(len(mine), nsets=2)
-    co = coadd.IncoherentCoadd(h, NANT, torch.device("cpu"), root=0, backend="gloo", order=order, layout=layout)
+    co = coadd.IncoherentCoadd(h, NANT, torch.device("cpu"), root=0, backend=transport, order=order, layout=layout)
     rc = host.run(args, rank=rank, world=world, local=0, rings=rings, handle=h, dist=dist, device=torch.device("cpu"), coadd=co)
     with open(os.path.join(tmp, "rc%d" % rank), "w") as f:
         f.write("%d %s" % (rc, [c for c in h.calls if c[0] in ("submit", "coadd_tree", "coadd_digitise", "coadd_publish")] + [("layout", co.layout)]))
     dist.barrier()
-    dist.destroy_process_group()
+    if transport == "gloo":
+        dist.destroy_process_group()
 
 
-def _run_world(tmp_path, world, NANT, order, layout="auto"):
+def _run_world(tmp_path, world, NANT, order, layout="auto", transport="gloo"):
     os.environ["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"),
                                                 os.environ.get("PYTHONPATH", "")])
     os.environ.setdefault("OMP_NUM_THREADS", "1")
+    tmp = str(tmp_path)
+    if transport == "threads":
+        # the ranks as threads of THIS process (vlite-fast_amd/threaded_ranks.py): the rehearsal transport for boxes
+        # that allow fewer processes on a card than configs[3] has ranks
+        tr = importlib.import_module("vlite-fast_amd.threaded_ranks")
+        tr.run_as_threads(world, lambda rank, w, dist: _worker(rank, w, 0, tmp, NANT, order, layout, "threads", dist), timeout=300)
+        for r in range(world):
+            assert (tmp_path / ("rc%d" % r)).read_text().startswith("0 ")
+        return
     ctx = mp.get_context("spawn")
     port = 29900 + (os.getpid() * 7 + world * 13 + NANT) % 2000
-    tmp = str(tmp_path)
     procs = [ctx.Process(target=_worker, args=(r, world, port, tmp, NANT, order, layout)) for r in range(world)]
     for p in procs:
         p.start()
@@ -213,14 +223,18 @@ def _quantise(tot, NANT):
     return (v.view(np.uint32) & np.uint32(0xFF)).astype(np.uint8).tobytes()
 
 
-@pytest.mark.parametrize("world,NANT,layout", [(8, 16, "auto"), (8, 16, "root"), (3, 7, "auto"), (5, 11, "auto"), (4, 6, "sliced"),
-                                               (2, 4, "root")])
-def test_coadd_host_tree_order_files_and_sum(tmp_path, world, NANT, layout):
+@pytest.mark.parametrize("world,NANT,layout,transport", [(8, 16, "auto", "gloo"), (8, 16, "root", "gloo"), (3, 7, "auto", "gloo"),
+                                                         (5, 11, "auto", "gloo"), (4, 6, "sliced", "gloo"), (2, 4, "root", "gloo"),
+                                                         (8, 16, "auto", "threads"), (8, 16, "root", "threads"),
+                                                         (3, 7, "auto", "threads")])
+def test_coadd_host_tree_order_files_and_sum(tmp_path, world, NANT, layout, transport):
     """(8, 16): two antennas per rank, configs[3] -- with the root's work spread over the ranks ("auto" -> "sliced":
     all-to-all of plane slices, every rank sums and requantises an eighth, code bytes gathered) and with every plane
     gathered to rank 0 ("root"): the SAME bytes; (3, 7) and (5, 11): worlds that are not powers of two ship every
-    antenna's plane, shards 3/2/2 and 3/2/2/2/2; (4, 6): a power of two with uneven shards 2/2/1/1"""
-    _run_world(tmp_path, world, NANT, "tree", layout)
+    antenna's plane, shards 3/2/2 and 3/2/2/2/2; (4, 6): a power of two with uneven shards 2/2/1/1.
+    transport "threads": the same ranks as threads of one process over torch's in-process group -- what the GPU test of
+    the 8 x 16 shape uses, where eight processes on one card are not allowed (tests/test_gpu_coadd_host.py)."""
+    _run_world(tmp_path, world, NANT, "tree", layout, transport)
     vdif, sigproc, dada, coadd, host = _mods()
     # the sum covers seconds 3600 and 3601: antenna 1's early second is skipped, antenna 2's stream ends with 3602,
     # which -- being its last -- is dropped

@@ -1,6 +1,8 @@
 """BASELINE configs[3] end to end on the GPU: the coadder host (vlite-fast_amd/coadd_host.py) started as 2, 3 or 4
-ranks (`--ranks N`, gloo rehearsal back end, all ranks on the one GPU this pool hands out), up to EIGHT antenna
-dumps, the rank's antennas batched in one handle -- pb_submit_vdif -> pb_process -> pb_coadd_local_tree ->
+ranks (`--ranks N`, gloo rehearsal back end, all ranks on the one GPU this pool hands out) and as EIGHT ranks x SIXTEEN
+antennas, two per rank -- configs[3]'s real shape -- with the ranks as threads of one process (`--dist-backend threads`,
+vlite-fast_amd/threaded_ranks.py: the pool lets at most six processes use a card, so eight gloo processes are not an
+option there), the rank's antennas batched in one handle -- pb_submit_vdif -> pb_process -> pb_coadd_local_tree ->
 dist.gather -> pb_coadd_tree + pb_coadd_finish on the root -- against the oracle:
   * every antenna's own .fil / _kur.fil byte for byte = header + the oracle's codes of that antenna's data;
   * the ONE coadded file `..._ea99_kur.fil` byte for byte = the station-99 SIGPROC header +
@@ -28,7 +30,7 @@ sigproc = importlib.import_module("vlite-fast_amd.sigproc")
 
 R, SEG = 8, 10
 NANT = 4
-STATIONS = [3, 8, 11, 27, 30, 41, 52, 63]
+STATIONS = [3, 8, 11, 27, 30, 41, 52, 63, 5, 9, 14, 22, 33, 47, 58, 61]
 
 
 def _dump(path, data, station):
@@ -42,11 +44,14 @@ def _dump(path, data, station):
             f.write(vdif.frame_block(p0, p1, 3600 + s, 33, station).tobytes())
 
 
-@pytest.mark.parametrize("nbit,NANT,ranks,order,layout", [(8, 8, 4, "tree", "auto"), (8, 8, 4, "tree", "root"), (8, 4, 2, "tree", "auto"),
-                                                          (2, 3, 2, "tree", "auto"), (4, 4, 2, "tree", "sliced"), (8, 5, 3, "tree", "auto"),
-                                                          (8, 4, 2, "fast", "auto")])
-def test_ranks_antennas_coadded_fil_is_byte_exact(tmp_path, oracle, nbit, NANT, ranks, order, layout):
-    """(4 ranks x 8 antennas: two per rank, configs[3]'s shape at half size; 2 ranks x 4: scale exactly 1/2; 2 bit,
+@pytest.mark.parametrize("nbit,NANT,ranks,order,layout,transport", [
+    (8, 16, 8, "tree", "auto", "threads"), (8, 16, 8, "tree", "root", "threads"),
+    (8, 8, 4, "tree", "auto", "gloo"), (8, 8, 4, "tree", "root", "gloo"), (8, 4, 2, "tree", "auto", "gloo"),
+    (2, 3, 2, "tree", "auto", "gloo"), (4, 4, 2, "tree", "sliced", "gloo"), (8, 5, 3, "tree", "auto", "gloo"),
+    (8, 4, 2, "fast", "auto", "gloo"), (2, 6, 4, "tree", "auto", "threads")])
+def test_ranks_antennas_coadded_fil_is_byte_exact(tmp_path, oracle, nbit, NANT, ranks, order, layout, transport):
+    """(8 ranks x 16 antennas, two per rank: configs[3] at its real shape, both layouts, the ranks as threads of one
+    process; 4 ranks x 8 antennas: the same at half size with gloo processes; 2 ranks x 4: scale exactly 1/2; 2 bit,
     3 antennas: ranks hold {0, 2} and {1}, scale float(1 / sqrt 3); 3 ranks x 5 antennas: not a power of two, every
     antenna's plane goes to the root; "fast": one dist.reduce of left-to-right local sums, whose two-rank association
     is known.  layout: with a power-of-two world and one output polarisation the root's work is spread over the ranks
@@ -60,7 +65,7 @@ def test_ranks_antennas_coadded_fil_is_byte_exact(tmp_path, oracle, nbit, NANT, 
         _dump(p, data[a], STATIONS[a])
         dumps.append(p)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, os.path.join(ROOT, "vlite-fast_amd", "coadd_host.py"), "--ranks", str(ranks), "--dist-backend", "gloo",
+    cmd = [sys.executable, os.path.join(ROOT, "vlite-fast_amd", "coadd_host.py"), "--ranks", str(ranks), "--dist-backend", transport,
            "--share-gpus", "--coadd-order", order, "--coadd-layout", layout, "--replay"] + dumps + ["-b", str(nbit), "-r", "2", "-w", "2", "--datadir", str(tmp_path),
            "--logdir", str(tmp_path / "logs"), "--rows-per-seg", str(R), "--out-sink", str(tmp_path / "co_ring.bin")]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
@@ -103,7 +108,8 @@ def test_ranks_antennas_coadded_fil_is_byte_exact(tmp_path, oracle, nbit, NANT, 
     assert want != b"".join(oracle.sel_and_dig(planes[0][s], R, nbit=nbit).tobytes() for s in range(nseg))
     log = "".join(open(os.path.join(str(tmp_path / "logs"), f)).read() for f in os.listdir(str(tmp_path / "logs")))
     assert 'order "%s"' % order in log
-    want_layout = "sliced" if (order == "tree" and ranks in (2, 4) and layout != "root") else "root"
+    want_layout = "sliced" if (order == "tree" and ranks in (2, 4, 8) and layout != "root") else "root"
+    assert ("rank %d of %d" % (ranks - 1, ranks)) in log
     assert 'layout "%s"' % want_layout in log
 
 

@@ -127,3 +127,68 @@ def test_rccl_world1_two_antennas_per_gpu_local_sum_path():
         h.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("A,target", [(1, True), (1, False), (2, False)])
+def test_rccl_world1_sliced_layout_runs_as_a_unit(A, target):
+    """The sliced layout's RCCL branch, executed inside coadd.IncoherentCoadd exactly as a multi-GPU rank runs it --
+    RCCL all_to_all_single of the plane slices -> pb_coadd_tree over the slices -> pb_coadd_digitise -> RCCL gather of
+    the code bytes -> pb_coadd_publish, all ordered on the leg's own stream, one batch behind the pipeline, with and
+    without the coadd-target shortcut -- in the only world an RCCL group can have on a one-GPU box: one rank
+    (`slice_world_of_one`, a test hook: the product only slices with more than one rank).  The published bytes must equal
+    what the single-rank form (`layout="root"`: pb_coadd_local_tree + pb_coadd_finish) gives for the same batches, and
+    the sel_and_dig of the antennas' own fp32 planes summed in the defined order.  What this cannot show is the
+    exchange between DIFFERENT ranks: that is the gloo / threaded tests' part (tests/test_gpu_coadd_host.py)."""
+    import importlib
+    import torch
+    import torch.distributed as dist
+    from helpers import parity_sum
+    lp = libpb()
+    cmod = importlib.import_module("vlite-fast_amd.coadd")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29050 + os.getpid() % 300)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        R, S, NSETS, NSTEP = 16, 4, 2, 3
+        data = [[make_input(110 + 10 * k + a, R, S) for a in range(A)] for k in range(NSTEP)]
+        got = {}
+        for layout in ("sliced", "root"):
+            h = lp.PbHandle(device=0, nant=A, nbit=8, npol=1, rfi_mode=2, rows_per_seg=R, max_seg=S, keep_ave=True, nsets=NSETS)
+            leg = cmod.IncoherentCoadd(h, A, dev, root=0, backend="nccl", order="tree", layout=layout, use_target=target,
+                                       slice_world_of_one=True)
+            assert leg.layout == layout and leg.world == 1 and leg.use_target == target
+            out, planes = [], []
+            for k in range(NSTEP + 1):
+                if k < NSTEP:
+                    h.select_set(k % NSETS)
+                    for a in range(A):
+                        for s in range(S):
+                            h.submit_planar(a, s, data[k][a][s, 0], data[k][a][s, 1])
+                    h.process(S)
+                if k >= 1:
+                    h.select_set((k - 1) % NSETS)
+                    h.fetch(0, 0, S)                                  # batch k - 1 is complete: its leg may be queued
+                    leg.queue((k - 1) % NSETS, S)
+                    if k >= 2:
+                        out.append(np.array(leg.coadded(S, age=1), copy=True))
+            out.append(np.array(leg.coadded(S, age=0), copy=True))
+            torch.cuda.synchronize()
+            if layout == "root":
+                for k in range(NSTEP):
+                    h.select_set(k % NSETS)
+                    if k >= NSTEP - NSETS:      # (the sets still hold the last NSETS batches' planes)
+                        planes.append((k, [h.fetch(a, 0, S, raw=False, kur=False, ave=True)["ave_kur"] for a in range(A)]))
+            got[layout] = (out, planes)
+            leg.close()
+            h.close()
+        for k in range(NSTEP):
+            assert np.array_equal(got["sliced"][0][k], got["root"][0][k]), "batch %d" % k
+        assert len(set(c.tobytes() for c in got["sliced"][0])) == NSTEP
+        for k, pl in got["root"][1]:
+            want = _sel_and_dig_8b(parity_sum(pl) * np.float32(1.0 / np.sqrt(float(A))))
+            assert np.array_equal(got["sliced"][0][k], want), "batch %d vs the planes" % k
+    finally:
+        dist.destroy_process_group()

@@ -119,7 +119,10 @@ KINDS = [("none",),
          ("none",)]
 if len(sys.argv) > 1:
     KINDS = [tuple(int(x) if x.lstrip("-").isdigit() else x for x in a.split(",")) for a in sys.argv[1:]]
-print("PB_SKIP=%s antennas=%d lib=%s" % (os.environ.get("PB_SKIP", "0"), A, os.path.basename(os.environ.get("PB_LIBPATH", "shipped"))))
+from bench import kernel_source_hash
+print("PB_SKIP=%s antennas=%d lib=%s kernel_source_sha16=%s" % (os.environ.get("PB_SKIP", "0"), A,
+                                                              os.path.basename(os.environ.get("PB_LIBPATH", "shipped")), kernel_source_hash()))
+DUR = float(os.environ.get("CORUN_MS", "250"))
 measure(("none",), 150.0)      # warm-up
 for kd in KINDS:
-    measure(kd)
+    measure(kd, DUR)

@@ -69,7 +69,8 @@ class IncoherentCoadd(object):
     handle: PbHandle(keep_ave=True, nsets=n) holding this rank's antennas.  The leg has a stream of its own
     (pb_set_coadd_stream): local sum -> gather / reduce -> the root's sum and requantisation of batch k are ordered
     on it by the device and run beside the kernels of the batches after it; nothing here synchronises the host except
-    the rehearsal back end ("gloo": the partial sums cross through host memory).
+    the rehearsal back ends ("gloo", and "threads" = W ranks as threads of one process, threaded_ranks.py: the partial
+    sums cross through host memory).
 
     order="tree" (default): the defined order of the module docstring -- pb_coadd_local_tree on every rank, a gather
     of the ranks' planes to the root, pb_coadd_tree there.  order="fast": pb_coadd_local (left to right over the
@@ -91,7 +92,7 @@ class IncoherentCoadd(object):
     """
 
     def __init__(self, handle, nant_total, device, root=0, backend="nccl", group=None, use_target=None, parts=7,
-                 source="planes", order="tree", layout="auto"):
+                 source="planes", order="tree", layout="auto", slice_world_of_one=False):
         if source not in ("planes", "codes"):
             raise ValueError("source must be 'planes' or 'codes'")
         if order not in ("tree", "fast"):
@@ -113,6 +114,8 @@ class IncoherentCoadd(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if root != 0 and order == "tree":
             raise ValueError("the tree order is rooted at rank 0")
+        if backend == "threads" and order == "fast" and self.world > 1:
+            raise ValueError("the threaded rehearsal group has no dist.reduce: order 'fast' needs nccl or gloo")
         A, W, N = handle.nant, self.world, self.nant_total
         n = self.n = handle.max_seg * handle.ave_per_seg
         # what a rank ships: its node of the tree (one plane) when the world is a power of two, otherwise every
@@ -120,7 +123,9 @@ class IncoherentCoadd(object):
         self.node_per_rank = order == "fast" or is_pow2(W)
         self.ship = 1 if self.node_per_rank else -(-N // W)
         if order == "tree":
-            if self.node_per_rank and len(antennas_of_rank(N, self.rank, W)) != A:
+            # whatever the world size: a handle with another antenna count than the sharding gives this rank would
+            # mis-address the root's leaves (a % W * ship + a // W) or, past `ship` planes, write beyond `sums`
+            if len(antennas_of_rank(N, self.rank, W)) != A:
                 raise ValueError("rank %d of %d holds %d antennas, the sharding a mod world gives it %d of %d"
                                  % (self.rank, W, A, len(antennas_of_rank(N, self.rank, W)), N))
             if max(A if self.node_per_rank else N, W) > 32:
@@ -137,10 +142,17 @@ class IncoherentCoadd(object):
                 handle.set_coadd_target(self.sums[st].data_ptr())
             handle.select_set(0)
         # "sliced": a power-of-two world of more than one rank, the tree order, one output polarisation (a flat range
-        # of the plane is then a range of the code stream)
-        can_slice = order == "tree" and W > 1 and is_pow2(W) and int(getattr(handle.cfg, "npol", 1)) == 1
+        # of the plane is then a range of the code stream).  slice_world_of_one (tests): also a world of ONE rank, so
+        # that the whole sliced leg -- all-to-all, tree over the slices, pb_coadd_digitise, gather of the code bytes,
+        # pb_coadd_publish, in stream order -- can run over RCCL on the one GPU a test box has.
+        can_slice = (order == "tree" and (W > 1 or slice_world_of_one) and is_pow2(W)
+                     and int(getattr(handle.cfg, "npol", 1)) == 1)
         if layout == "sliced" and not can_slice:
             raise ValueError("the sliced layout needs the tree order, a power-of-two world > 1 and npol = 1")
+        if layout == "sliced" and parts != 7:
+            raise ValueError("parts (timing experiments) isolates steps of the 'root' layout only: use layout='root'")
+        if parts != 7 and layout == "auto":
+            layout = "root"
         self.layout = "sliced" if (can_slice and layout != "root") else "root"
         self.gath = self.total = self.leaves = None
         if self.layout == "sliced":

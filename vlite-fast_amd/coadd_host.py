@@ -69,7 +69,9 @@ def build_parser():
     p.add_argument("--nsets", type=int, default=2)
     p.add_argument("--ranks", type=int, default=0, help="start this many ranks (one per GPU) as child processes")
     p.add_argument("--master-port", type=int, default=0)
-    p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal: reduce through host memory)")
+    p.add_argument("--dist-backend", default="nccl",
+                   help="nccl (= RCCL, default); rehearsals: gloo (processes, collectives through host memory) or threads "
+                        "(with --ranks N: the N ranks as threads of THIS process, for boxes that allow few processes on a card)")
     p.add_argument("--coadd-input", choices=["planes", "codes"], default="planes",
                    help="what is summed: the fp32 planes before quantisation (default) or the antennas' quantised codes")
     p.add_argument("--coadd-order", choices=["tree", "fast"], default="tree",
@@ -108,7 +110,7 @@ class Control(object):
         self.dist = dist
         self.group = None
         if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-            self.group = dist.new_group(backend="gloo") if backend != "gloo" else dist.group.WORLD
+            self.group = dist.new_group(backend="gloo") if backend == "nccl" else dist.group.WORLD
             self.on = True
         else:
             self.on = False
@@ -138,7 +140,7 @@ def run(args, rank=0, world=1, local=0, rings=None, handle=None, dist=None, devi
     if nant < world:
         raise SystemExit("coadd_host: %d antenna stream(s) for %d ranks; every rank needs at least one" % (nant, world))
     mine = cmod.antennas_of_rank(nant, rank, world)
-    _log = pbmod.Log(args.logdir, args.stdout_output)
+    _log = pbmod.Log(args.logdir, args.stdout_output, suffix="_rank%d" % rank if args.dist_backend == "threads" else "")
 
     def log(level, msg):
         _log(level, msg)
@@ -372,11 +374,33 @@ def run(args, rank=0, world=1, local=0, rings=None, handle=None, dist=None, devi
     return exit_status
 
 
+def run_threaded(args):
+    """`--dist-backend threads --ranks N`: the N ranks as threads of this process (threaded_ranks.py), every rank with a
+    handle and a coadd leg of its own on the one card -- the rehearsal for boxes that allow fewer processes on a GPU
+    than configs[3] has ranks.  -> the largest exit status of the ranks."""
+    import torch
+    if torch.cuda.device_count() < 1 or not torch.cuda.is_available():
+        raise SystemExit("coadd_host needs a GPU: the HIP path has no CPU fallback")
+    if not args.share_gpus:
+        raise SystemExit("coadd_host: --dist-backend threads puts every rank on one card: a rehearsal, say --share-gpus")
+    tr = importlib.import_module(_pkg + ".threaded_ranks")
+    world = max(1, args.ranks)
+    dev = torch.device("cuda", 0)
+
+    def body(rank, world, dist):
+        torch.cuda.set_device(0)
+        return run(args, rank=rank, world=world, local=0, dist=dist if world > 1 else None, device=dev)
+
+    return max(tr.run_as_threads(world, body))
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = build_parser().parse_args(argv)
     if not args.replay and not args.keys_in:
         raise SystemExit("coadd_host: give the antenna streams with --replay FILE... or -k KEY...")
+    if args.dist_backend == "threads":
+        sys.exit(run_threaded(args))
     if "WORLD_SIZE" not in os.environ and args.ranks > 1:
         sys.exit(launch_ranks(args, argv))
     rank = int(os.environ.get("RANK", "0"))

@@ -124,10 +124,11 @@ def validate(args):
 class Log(object):
     """multilog stand-in: timestamped lines to the per-process log file and optionally stdout."""
 
-    def __init__(self, logdir, to_stdout):
+    def __init__(self, logdir, to_stdout, suffix=""):
         self.fps = []
         stamp = time.strftime("%Y%m%d_%H%M%S", time.gmtime())
-        path = os.path.join(logdir, "%s_%s_process_%06d.log" % (stamp, socket.gethostname(), os.getpid()))
+        # (suffix: ranks that share one process -- the threaded rehearsal of coadd_host.py -- get a file each)
+        path = os.path.join(logdir, "%s_%s_process_%06d%s.log" % (stamp, socket.gethostname(), os.getpid(), suffix))
         try:
             os.makedirs(logdir, exist_ok=True)
             self.fps.append(open(path, "w"))
