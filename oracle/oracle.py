@@ -398,3 +398,78 @@ def optimize_pulse(ts, i0, i1, wmax=32):
         locs[iw] = a + w
         sns[iw] = (sts[a] - mean) / std * w ** 0.5
     return widths, sns, locs
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The downstream search's checker (BASELINE config 5).  heimdall / dedisp are third-party and absent from
+# /root/reference (parity with heimdall's candidate list is UNPINNED, DESIGN.md 4.5); what the reference itself holds
+# about this stage is restated here and used by tests/test_gpu_search.py:
+#   * incoherent dedispersion = every channel shifted by its dispersion delay, then summed over channels
+#     (analysis/loc_step0.py:44-66, the roll; the per-channel delay formula with the constant of src/candidate.py:33);
+#   * the S/N estimator: off-pulse median and Qn, (running mean - median) / Qn * sqrt(w)
+#     (analysis/loc_step0.py:120-147 with analysis/utils.py:74-122, 187-195);
+#   * the candidate line's nine columns (src/candidate.py:8-18).
+
+DM_CONST = 4.148808e3          # src/candidate.py:33: dm_delay = 4.148808e3 * dm * |f0^-2 - f1^-2| (MHz, seconds)
+
+
+def search_delays(dms, fch1, foff, nchan, tsamp):
+    """[ndm][nchan] delays in samples relative to the first (highest) channel: the formula of src/candidate.py:33 per
+    channel, rounded half up (floor(x + 0.5): the delays are >= 0, where it equals analysis/loc_step0.py:62's
+    np.round except on exact halves)."""
+    f = fch1 + foff * np.arange(nchan)
+    return np.stack([np.floor(DM_CONST * dm * (f ** -2 - f[0] ** -2) / tsamp + 0.5).astype(int) for dm in dms])
+
+
+def dedisperse_series(codes, delays, zap):
+    """codes [T][nchan] (SIGPROC time-major 8-bit), delays [ndm][nchan], zap [nchan] bool -> ([ndm][tout] exact integer
+    sums, tout).  analysis/loc_step0.py:44-66 rolls channel c by -delay[c] and the caller sums over channels; this is
+    that sum over the samples no roll wraps around (tout = T - the largest delay of a kept channel): a slice per
+    channel instead of an in-place roll, the same numbers (tests/test_oracle_golden.py ties the two together)."""
+    T, nchan = codes.shape
+    ndm = delays.shape[0]
+    maxd = max(int(delays[i][~zap].max()) for i in range(ndm))
+    tout = T - maxd
+    series = np.zeros((ndm, tout), np.uint32)
+    x = codes.astype(np.uint32)
+    for i in range(ndm):
+        for c in range(nchan):
+            if not zap[c]:
+                series[i] += x[delays[i, c]:delays[i, c] + tout, c]
+    return series, tout
+
+
+def boxcar_best(x, mean, rms, nbox):
+    """best S/N over the boxcar widths 2^0 .. 2^(nbox-1) starting at every sample, from a given level and rms:
+    (sum of w samples - w mean) / (rms sqrt(w)) -- the running-mean form of analysis/loc_step0.py:143-146,
+    (mean_w - level) / sigma * w^0.5, written with sums.  -> (best S/N per start sample, log2 of its width)"""
+    x = np.asarray(x, np.float64)
+    tout = x.size
+    best = np.full(tout, -1e30)
+    bw = np.zeros(tout, int)
+    c = np.concatenate([[0], np.cumsum(x)])
+    for k in range(nbox):
+        w = 1 << k
+        sn = np.full(tout, -1e30)
+        sn[:tout - w + 1] = (c[w:] - c[:-w] - w * float(mean)) / (float(rms) * np.sqrt(w))
+        upd = sn > best
+        best[upd], bw[upd] = sn[upd], k
+    return best, bw
+
+
+def pulse_sn(ts, i0, i1, start, w):
+    """The reference's S/N definition (analysis/loc_step0.py:120-147) for ONE given boxcar: level = median and sigma =
+    Qn (analysis/utils.py:187-195) of the first and last quarter of ts[i0:i1], S/N = (mean of the w samples from
+    `start` - level) / sigma * sqrt(w).  optimize_pulse itself only tries ODD widths, because tophat_smooth forces them
+    (analysis/utils.py:84-86); this evaluates the same estimator at the width and position a search reports."""
+    ts = np.asarray(ts, np.float64)
+    nsamp = i1 - i0
+    s = np.append(ts[i0:i0 + int(nsamp * 0.25)], ts[i0 + int(nsamp * 0.75):i1])
+    return (ts[start:start + w].mean() - np.median(s)) / qn(s) * w ** 0.5
+
+
+def candidate_columns(line):
+    """the nine columns of a heimdall candidate line as src/candidate.py:8-18 reads them"""
+    t = line.split()
+    return dict(sn=float(t[0]), peak_idx=int(t[1]), peak_time=float(t[2]), tfilt=int(t[3]), dmi=int(t[4]), dm=float(t[5]),
+                ngiant=int(t[6]), i0=int(t[7]), i1=int(t[8]), ncol=len(t))

@@ -1,7 +1,9 @@
-"""Dedispersion + boxcar search (BASELINE config 5) on the GPU: integer arithmetic bit-exact against
-a NumPy restatement, S/N of an injected dispersed pulse consistent with the reference's own
-estimator (analysis/loc_step0.py, pinned by tests/golden), candidate lines parse with the
-reference's src/candidate.py column order."""
+"""Dedispersion + boxcar search (BASELINE config 5) on the GPU, against oracle/oracle.py's search section only: integer
+dedispersion bit-exact against oracle.dedisperse_series (the roll-and-sum of analysis/loc_step0.py:44-66 with the delay
+constant of src/candidate.py:33), the boxcar S/N planes against oracle.boxcar_best, the S/N of an injected dispersed
+pulse within 5 % of the reference's own estimator definition (median / Qn / sqrt(w), analysis/loc_step0.py:120-147,
+pinned by tests/golden) evaluated on the same series at the reported width, candidate lines parsed with the reference's
+column order (src/candidate.py:8-18).  heimdall itself is third-party and absent: its candidate list is unpinned."""
 import importlib
 
 import numpy as np
@@ -24,21 +26,7 @@ def _plane(seed, T, nchan, dm, t0, width, amp, fch1, foff, tsamp):
     return np.clip(np.floor(g / 0.02957 + 127.5), 0, 255).astype(np.uint8), delay
 
 
-def _numpy_search(codes, nchan, delays, zap, nbox):
-    T = codes.shape[0]
-    ndm = delays.shape[0]
-    maxd = max(int(delays[i][~zap].max()) for i in range(ndm))
-    tout = T - maxd
-    series = np.zeros((ndm, tout), np.uint32)
-    x = codes.astype(np.uint32)
-    for i in range(ndm):
-        for c in range(nchan):
-            if not zap[c]:
-                series[i] += x[delays[i, c]:delays[i, c] + tout, c]
-    return series, tout
-
-
-def test_dedisperse_and_boxcar_small():
+def test_dedisperse_and_boxcar_small(oracle):
     nchan, T, tsamp = 256, 2048, search.TSAMP
     fch1, foff = 361.94, -0.16
     codes, _ = _plane(71, T, nchan, dm=40.0, t0=700, width=4, amp=0.8, fch1=fch1, foff=foff, tsamp=tsamp)
@@ -47,27 +35,18 @@ def test_dedisperse_and_boxcar_small():
                          dm_step=4.0, boxcar_max=16, zap=zap) as s:
         r = s.run(codes, want_series=True)
         dms, nbox, maxd = s.dms, s.nbox, s.max_delay
-    f = fch1 + foff * np.arange(nchan)
-    delays = np.stack([np.floor(4.148808e3 * dm * (f ** -2 - f[0] ** -2) / tsamp + 0.5).astype(int) for dm in dms])
+    delays = oracle.search_delays(dms, fch1, foff, nchan, tsamp)
     zmask = np.zeros(nchan, bool)
     for lo, hi in zap:
         zmask[lo:hi] = True
-    ref, tout = _numpy_search(codes, nchan, delays, zmask, nbox)
+    ref, tout = oracle.dedisperse_series(codes, delays, zmask)
     assert tout == r["tout"] and maxd == int(delays[-1][~zmask].max())
     assert np.array_equal(r["series"], ref)                        # dedispersion: exact integers
     # boxcar S/N from the kernel's own (clipped) mean and rms
     i = 10                                                          # DM 40
     mean, rms = r["stats"][i]
     x = ref[i].astype(np.float64)
-    best = np.full(tout, -1e30)
-    bw = np.zeros(tout, int)
-    for k in range(nbox):
-        w = 1 << k
-        c = np.concatenate([[0], np.cumsum(x)])
-        sn = np.full(tout, -1e30)
-        sn[:tout - w + 1] = (c[w:] - c[:-w] - w * float(mean)) / (float(rms) * np.sqrt(w))
-        upd = sn > best
-        best[upd], bw[upd] = sn[upd], k
+    best, bw = oracle.boxcar_best(x, mean, rms, nbox)
     np.testing.assert_allclose(r["snr"][i], best, rtol=2e-5, atol=2e-4)
     mad = 1.4826 * np.median(np.abs(x - np.median(x)))              # robust sigma (the pulse inflates x.std())
     assert abs(float(mean) - np.median(x)) < 0.1 * mad and 0.9 < float(rms) / mad < 1.1
@@ -91,16 +70,24 @@ def test_config5_full_band_candidates(oracle):
     top = cands[0]
     assert abs(top["dm"] - dm) <= 10.0 and abs(top["peak_idx"] - t0) <= 4 and 1 <= top["tfilt"] <= 3
     assert top["snr"] > 3 * max([c["snr"] for c in cands[1:]] + [0.0]) or len(cands) == 1
-    # S/N cross-check with the reference's estimator (median / Qn / top-hat) on the same series
-    i = int(np.argmin(np.abs(dms - dm)))
+    # S/N against the reference's estimator DEFINITION (off-pulse median and Qn, running mean, sqrt(w):
+    # analysis/loc_step0.py:120-147) on the search's own dedispersed series, at the boxcar the search reports -- the
+    # two then differ only in how level and sigma are estimated (3-sigma clipped mean / rms of the whole series here,
+    # median / Qn of 2048 off-pulse samples there): within 5 %.  (optimize_pulse itself, which can only try odd widths,
+    # lands 10 - 15 % lower on this 4-sample pulse: its best are w = 3 and w = 5.)
+    i = top["dmi"]
     ts = r["series"][i].astype(np.float64)
+    k = np.unravel_index(np.argmax(r["snr"]), r["snr"].shape)
+    assert k[0] == i
+    w = 1 << int(r["width_log2"][k])
+    ref_sn = oracle.pulse_sn(ts, t0 - 2048, t0 + 2048, int(k[1]), w)
+    assert abs(top["snr"] / ref_sn - 1.0) < 0.05, (top["snr"], ref_sn, w)
     widths, sns, locs = oracle.optimize_pulse(ts, t0 - 128, t0 + 128, wmax=16)
-    ref_sn = float(sns.max())
-    assert 0.8 < top["snr"] / ref_sn < 1.25, (top["snr"], ref_sn)
+    assert 0.75 < float(sns.max()) / ref_sn < 1.1 and widths[int(np.argmax(sns))] in (3, 5)
     # candidate line: the reference's parser column order (src/candidate.py:8-18)
-    toks = search.candidate_line(top).split()
-    assert abs(float(toks[0]) - top["snr"]) < 1e-3 and int(toks[1]) == top["peak_idx"] and int(toks[4]) == top["dmi"]
-    assert abs(float(toks[5]) - top["dm"]) < 1e-3 and int(toks[7]) <= top["peak_idx"] < int(toks[8]) and len(toks) == 9
+    col = oracle.candidate_columns(search.candidate_line(top))
+    assert abs(col["sn"] - top["snr"]) < 1e-3 and col["peak_idx"] == top["peak_idx"] and col["dmi"] == top["dmi"]
+    assert abs(col["dm"] - top["dm"]) < 1e-3 and col["i0"] <= top["peak_idx"] < col["i1"] and col["ncol"] == 9
 
 
 def test_peak_list_equals_thresholded_planes_and_bad_arguments():
@@ -182,10 +169,10 @@ def test_wide_pulse_just_before_a_gulp_boundary_gets_its_full_width():
     assert top["snr"] > 0.9 * whole["snr"]
 
 
-def test_search_without_zap_at_full_block_length():
+def test_search_without_zap_at_full_block_length(oracle):
     """no zapped channels, nsamp == max_samples and tout a little past a multiple of the 2048-sample
     tile: lanes past the last output sample must not load (they used to read up to a tile past the last channel's
-    row).  Integer series against NumPy."""
+    row).  Integer series against oracle.dedisperse_series."""
     nchan, tsamp = 64, search.TSAMP
     fch1, foff = 361.94, -0.5
     with search.Searcher(nchan=nchan, max_samples=4096, fch1=fch1, foff=foff, tsamp=tsamp, dm_min=0.0, dm_max=30.0,
@@ -197,9 +184,8 @@ def test_search_without_zap_at_full_block_length():
                          dm_step=10.0, boxcar_max=4, zap=()) as s:
         assert s.max_delay == maxd
         r = s.run(codes, want_series=True)
-        f = fch1 + foff * np.arange(nchan)
-        delays = np.stack([np.round(4.148808e3 * dm * (f ** -2 - f[0] ** -2) / tsamp).astype(int) for dm in s.dms])
-    series, tout = _numpy_search(codes, nchan, delays, np.zeros(nchan, bool), 3)
+        delays = oracle.search_delays(s.dms, fch1, foff, nchan, tsamp)
+    series, tout = oracle.dedisperse_series(codes, delays, np.zeros(nchan, bool))
     assert tout == 2056 and np.array_equal(r["series"], series)
 
 

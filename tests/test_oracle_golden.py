@@ -220,3 +220,37 @@ def test_dagostino_score_is_the_published_anscombe_glynn_statistic(oracle):
                 err = abs(float(dag[0]) - abs(z)) / max(1.0, abs(z))
                 worst = max(worst, err)
     assert worst < 2e-4, worst
+
+
+def test_search_checker_is_the_pinned_roll_and_estimator(golden, oracle):
+    """oracle.py's search section (what tests/test_gpu_search.py holds the GPU search to) against the functions the
+    reference fixtures pin: dedisperse_series == every channel rolled by -delay with the pinned inplace_roll
+    (analysis/utils.py:4-17, as analysis/loc_step0.py:44-66 applies it) and summed over the kept channels, on the samples
+    no roll wraps; pulse_sn at an odd width == the S/N optimize_pulse (pinned by s1_sns) assigns to that width at its
+    best position; the candidate columns of src/candidate.py:8-18."""
+    rng = np.random.default_rng(5)
+    T, nchan = 700, 24
+    codes = rng.integers(0, 256, (T, nchan)).astype(np.uint8)
+    dms = np.array([0.0, 35.0, 80.0])
+    delays = oracle.search_delays(dms, 361.94, -1.3, nchan, 781.25e-6)
+    assert delays[0].max() == 0 and delays[2].max() > 40 and np.all(np.diff(delays[2]) >= 0)
+    zap = np.zeros(nchan, bool)
+    zap[[0, 7]] = True
+    series, tout = oracle.dedisperse_series(codes, delays, zap)
+    assert tout == T - int(delays[2][~zap].max())
+    for i in range(len(dms)):
+        plane = codes.T.astype(np.int64).copy()                       # channel x time, like the reference's arrays
+        for c in range(nchan):
+            oracle.inplace_roll(plane[c], -int(delays[i, c]))
+        assert np.array_equal(series[i], plane[~zap].sum(axis=0)[:tout].astype(np.uint32)), i
+    ts, i0, i1 = golden["s1_ts"], int(golden["s1_params"][9]), int(golden["s1_params"][10])
+    widths, sns, locs = oracle.optimize_pulse(ts, i0, i1)
+    for iw in (0, 1, 2):                                               # widths 1, 3, 5
+        w = int(widths[iw])
+        centre = i0 + int(locs[iw])                                   # tophat_smooth centres its window
+        got = oracle.pulse_sn(ts, i0, i1, centre - w // 2, w)
+        np.testing.assert_allclose(got, golden["s1_sns"][iw], rtol=1e-9)
+    best, bw = oracle.boxcar_best(np.array([0., 0., 5., 5., 0., 0.]), 0.0, 1.0, 2)
+    assert best[2] == 10.0 / np.sqrt(2.0) and bw[2] == 1 and best[3] == 5.0 and bw[3] == 0
+    col = oracle.candidate_columns("12.5 3000 2.34 2 30 302.0 17 2996 3010")
+    assert col == dict(sn=12.5, peak_idx=3000, peak_time=2.34, tfilt=2, dmi=30, dm=302.0, ngiant=17, i0=2996, i1=3010, ncol=9)

@@ -37,7 +37,7 @@ static int resident(int lds, int threads, int nwg)
     std::map<unsigned long long, std::vector<std::pair<unsigned long long, int>>> ev;
     for (int i = 0; i < nwg; ++i) {
         const unsigned long long hw = h[i * 4 + 3];
-        const unsigned long long cu = (h[i * 4 + 2] << 16) | (((hw >> 8) & 0xf) << 4) | ((hw >> 13) & 0x7) | (((hw >> 16) & 0x3) << 8);  // CU_ID, SE_ID, SH
+        const unsigned long long cu = (h[i * 4 + 2] << 16) | ((hw >> 8) & 0xff);      // XCC, then HW_ID[15:8] = SE_ID, SH_ID, CU_ID
         ev[cu].push_back({h[i * 4 + 0], +1});
         ev[cu].push_back({h[i * 4 + 1], -1});
     }

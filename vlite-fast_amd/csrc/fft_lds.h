@@ -371,11 +371,22 @@ __device__ __forceinline__ f2 rsplit(const f2 *buf, const f2 *__restrict__ post,
 __device__ __forceinline__ void read_z_pairs(const f2 *buf, int k0, f2 (&za)[4], f2 (&zb)[4])
 {
     typedef float f4v __attribute__((ext_vector_type(4)));
+#ifdef FFT_ZCONF_ABL
+    // timing experiment (variant builds only, RESULTS INVALID): the same five reads at conflict-free addresses (lane
+    // stride 8 / 16 bytes) -- what the step's 4-way (8-byte) and 2-way (16-byte) bank conflicts cost
+    const int l = threadIdx.x;
+    const f2 za0 = buf[l + (k0 & 1024)];
+    const f4v za12 = *(const f4v *)(buf + 2 * l + 512);
+    const f2 za3 = buf[l + 256 + (k0 & 1024)];
+    const f4v zb10 = *(const f4v *)(buf + 2 * l + 2048);
+    const f4v zb32 = *(const f4v *)(buf + 2 * l + 3072);
+#else
     const f2 za0 = buf[k0];
     const f4v za12 = *(const f4v *)(buf + k0 + 1);
     const f2 za3 = buf[k0 + 3 == M_HALF ? 0 : k0 + 3];
     const f4v zb10 = *(const f4v *)(buf + (M_HALF - k0 - 1));
     const f4v zb32 = *(const f4v *)(buf + (M_HALF - k0 - 3));
+#endif
     za[0] = za0;
     za[1] = mk2(za12.x, za12.y);
     za[2] = mk2(za12.z, za12.w);

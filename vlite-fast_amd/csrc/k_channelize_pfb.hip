@@ -27,7 +27,9 @@
 #ifndef PFB_DBG
 #define PFB_DBG 0     // timing experiments only: 1 no coefficient loads, 2 one tap only, 4 stage one row only
 #endif
+#ifndef PFB_ROW_LDS
 #define PFB_ROW_LDS 12528    // 12500 bytes + up to 12 of alignment slack, padded to 16
+#endif
 #define PFB_HIST_STRIDE 12512
 #ifndef PFB_STAGE_DMA
 #define PFB_STAGE_DMA 1      // rows go to LDS by global_load_lds_dwordx4 (0: through registers; timing experiments)

@@ -37,6 +37,7 @@
 //
 // HBM traffic: the power planes (4 B per row x channel x pol x stream) once; outputs 1/64 of it.
 #include <cstdlib>
+#include <type_traits>
 
 #include "pb_internal.h"
 
@@ -583,6 +584,350 @@ static void launch_mode(const Detect2Args &a, int mode, dim3 grid, hipStream_t s
     else k_detect2<T, NPOL, NBIT, 2, DEPTH><<<grid, D2_THREADS, 0, st>>>(a);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_detect3 (round 6): BOTH streams in one workgroup, so that a launch is 128 workgroups instead of 256.
+//
+// Why: what bounds the pipelined step is how many workgroups a CU holds (profiles/r05_notes.md section 1): a detect
+// workgroup of either form takes the place of one 50-KB channeliser workgroup on its CU for as long as it lives.
+// k_detect2 is one workgroup per (32 channels, stream): 256 x 0.24 ms of such slots per second of data.  With half of
+// them left out (timing experiment, results invalid) the step is 14 % shorter (profiles/r06_notes.md).  This kernel keeps
+// all the work and halves the slots: one workgroup = 32 channels x 2 pols x BOTH streams, ten waves (the registers a
+// displaced channeliser workgroup frees on a CU hold them: <= 56 VGPRs each, three per SIMD beside two channeliser
+// workgroups), chunks of 16 rows, one barrier per chunk step:
+//   loader (wave 6): LDS-DMA of the chunk's 2 x 16 rows x 64 columns into a ring slot, DEPTH chunks ahead;
+//   A  (wave 2; lane = (pol, channel)): BOTH recurrences side by side in packed registers (raw, excised): per row one
+//      packed multiply (1-s) bp, one packed multiply s p (of the next row), one packed add, and the excised half's clip
+//      test (11 bp, compare, select) -- the same IEEE operations on the same operands as k_detect2's two recurrence
+//      waves, hence the same bits; bp after every row goes to LDS as one 8-byte store (raw, excised);
+//   B  (the other eight waves): wave -> (chunk parity, 8-row group, stream), lane -> (half of the group's rows, channel),
+//      both pols.  Everything that only needs (p, bp) of its own rows as in k_detect2 -- clip test again, division, pol
+//      scrunch in double, weighted time scrunch, quantiser.  The 8-row time scrunch is a SEQUENTIAL fp32 sum over the
+//      rows: lanes of half 0 sum rows 0-3 from +0.0, hand the partial sum to their partner lane (half 1, lane + 32),
+//      which adds its four terms on top in order and finishes -- the same additions in the same order as one lane
+//      walking eight rows.  A B wave takes chunk c into registers at step c+1 (rows 0-1 of its half) and finishes it at
+//      step c+2, while the waves of the other parity take chunk c+1.
+// LDS: ring (DEPTH + 2) x 8 KB + 16 KB of bp + 1.2 KB = 58.6 KB at DEPTH 3: the same 46 allocation granules of 1 280 B
+// as k_detect2's three-chunk ring (tools/lds_granule.hip measures the granule).
+// Used for RFI mode 2 when rows_per_seg is a multiple of 16; everything else stays with k_detect2.
+#ifndef PB_DETECT3
+#define PB_DETECT3 0            // 1: launch_detect_pow takes this kernel where it applies
+#endif
+#define D3_T 16
+#define D3_THREADS 640
+#define D3_WAVE_A 2             // waves w and w + 4 (and w + 8) share a SIMD: A and the loader get one to themselves
+#define D3_WAVE_L 6
+#ifndef D3_VGPRS
+#define D3_VGPRS 56
+#endif
+
+namespace {
+typedef float d3f2 __attribute__((ext_vector_type(2)));
+
+// which phase-B wave (0..7) a wave of the ten is, or -1
+__device__ __forceinline__ int d3_b_index(int wave)
+{
+    // waves 0 1 3 4 5 7 8 9 -> 0..7
+    return wave == D3_WAVE_A || wave == D3_WAVE_L ? -1 : wave - (wave > D3_WAVE_A ? 1 : 0) - (wave > D3_WAVE_L ? 1 : 0);
+}
+
+template <int NPOL> struct B3State {
+    float p[2][4], u[2][4], uprev[2];
+    float w[4];                    // weights of this lane's four rows (excised stream)
+    float term[2][4];              // what each row adds to the time scrunch (per output pol)
+    float wt_sumf;
+    int wt_sum, trow, seg;
+};
+
+// rows j0, j0 + 1 of the lane's four
+template <int NPOL, bool KUR>
+__device__ __forceinline__ void d3_rows(B3State<NPOL> &s, int j0)
+{
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int j = j0 + jj;
+        float x[2];
+        const float w = KUR ? s.w[j] : 1.f;
+#pragma unroll
+        for (int pol = 0; pol < 2; ++pol) {
+            const float un = s.u[pol][j];
+            const float ub = j == 0 ? s.uprev[pol] : s.u[pol][j ? j - 1 : 0];
+            const float p = s.p[pol][j];
+            float v = p / un - 1.f;
+            if (KUR) {
+                v = p > ub * 11.f ? 10.f : v;          // the recurrence wave's own test (:490-491): clipped -> 10
+                v = w == 0.f ? 0.f : v;                // :474-476
+            }
+            x[pol] = v;
+        }
+        if (NPOL == 1) {
+            const float sum = x[0] + x[1];
+            const float y = (float)(M_SQRT1_2 * (double)sum);
+            if (!KUR) {
+                s.term[0][j] = y;
+            } else {
+                const bool ok = w >= 0.2f;           // MIN_WEIGHT, both pols share the row weight
+                const float prod = w * y;
+                s.term[0][j] = ok ? prod : 0.f;
+            }
+        } else {
+            if (!KUR) {
+                s.term[0][j] = x[0];
+                s.term[1][j] = x[1];
+            } else {
+                const bool ok = !(w < 0.2f);
+                const float pr0 = w * x[0], pr1 = w * x[1];
+                s.term[0][j] = ok ? pr0 : 0.f;
+                s.term[1][j] = ok ? pr1 : 0.f;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+template <int NPOL, int NBIT, int DEPTH>
+__global__ __launch_bounds__(D3_THREADS) __attribute__((amdgpu_num_vgpr(D3_VGPRS))) void k_detect3(Detect2Args a)
+{
+    constexpr int T = D3_T, NG = T / PB_NSCRUNCH, LPC = 2 * (T / 4);
+    __shared__ __attribute__((aligned(16))) float s_p[D2_NSLOT][2][T][64];     // [slot][stream][row][pol * 32 + channel]
+    __shared__ __attribute__((aligned(16))) d3f2 s_u[2][T][64];                // bp after each row: (raw, excised)
+    __shared__ d3f2 s_u0[2][64];                                               // bp before the chunk's first row
+    __shared__ float s_w[3][T];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int cg = blockIdx.x, ant = blockIdx.z;
+    const int R = a.R, cps = R / T, nchunk = a.nseg * cps, nstep = nchunk + 2;
+    const int ntime = R / PB_NSCRUNCH;
+    const float *wrow = a.wrow + (size_t)ant * a.S * R;
+    const size_t pol_stride = (size_t)R * PB_NCHANOUT, seg_stride = 2 * pol_stride;
+    const float *Pant[2] = {a.P[0] + (size_t)ant * a.S * seg_stride, a.P[1] + (size_t)ant * a.S * seg_stride};
+    const int bi = d3_b_index(wave);
+
+    if (wave == D3_WAVE_L) {
+        // ---- loader: lane -> (row in group of 4, pol, 4 channels); one instruction = 4 rows x 64 columns of one stream
+        const int ld_row = lane >> 4, ld_pol = (lane >> 3) & 1, ld_c = cg * 32 + (lane & 7) * 4;
+        const size_t loff = (size_t)ld_pol * pol_stride + (size_t)ld_row * PB_NCHANOUT + ld_c;
+        auto issue = [&](const Cursor<DEPTH> &cu) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const float *src = Pant[st] + (size_t)cu.seg * seg_stride + (size_t)(cu.rb * T) * PB_NCHANOUT + loff;
+#pragma unroll
+                for (int i = 0; i < T / 4; ++i)
+                    __builtin_amdgcn_global_load_lds(
+                        (const void __attribute__((address_space(1))) *)(src + (size_t)(4 * i) * PB_NCHANOUT),
+                        (void __attribute__((address_space(3))) *)&s_p[cu.slot][st][4 * i][0], 16, 0, D2_LOAD_AUX);
+            }
+        };
+        auto wait_chunks = [&](int n) {
+            if (n <= 0) wait_vmcnt<0>();
+            else if (n == 1) wait_vmcnt<LPC>();
+            else wait_vmcnt<(DEPTH - 1) * LPC>();           // (DEPTH <= 3: n == 2)
+        };
+        Cursor<DEPTH> cu;
+        cu.init(0, cps);
+        auto fill = [&](int upto) {
+            while (cu.c < nchunk && cu.c < upto) {
+                issue(cu);
+                cu.next(cps);
+            }
+        };
+        fill(DEPTH);
+        wait_chunks(cu.c - 1);                       // chunk 0 has landed
+        step_barrier_raw();
+        for (int k = 0; k < nstep; ++k) {
+            fill(k + 1 + DEPTH);
+            wait_chunks(cu.c - (k + 2));             // chunk k + 1 has landed
+            step_barrier_raw();
+        }
+    } else if (wave == D3_WAVE_A) {
+        // ---- A: both recurrences.  lane -> (pol, channel); registers carry (raw, excised) pairs
+        __builtin_amdgcn_s_setprio(D2_PRIO_A);
+        const int polA = lane >> 5, cA = cg * 32 + (lane & 31);
+        const float *inA[2] = {Pant[0] + (size_t)polA * pol_stride + cA, Pant[1] + (size_t)polA * pol_stride + cA};
+        float *bpp0 = a.bp + (((size_t)ant * 2 + 0) * 2 + polA) * PB_NCHANOUT + cA;
+        float *bpp1 = a.bp + (((size_t)ant * 2 + 1) * 2 + polA) * PB_NCHANOUT + cA;
+        d3f2 bp = {*bpp0, *bpp1};
+        const d3f2 sc2 = {a.scale, a.scale}, om2 = {a.oms, a.oms};
+        Cursor<DEPTH> cu;
+        cu.init(0, cps);
+        step_barrier_raw();
+        float wv_next = (lane < T && nchunk > 0) ? wrow[lane] : 1.f;
+        for (int k = 0; k < nstep; ++k) {
+            if (k < nchunk) {
+                const int slot = cu.slot, buf = k & 1;
+                {
+                    const float wv = wv_next;
+                    if (k + 1 < nchunk && lane < T) wv_next = wrow[(size_t)(k + 1) * T + lane];
+                    if (lane < T) s_w[k % 3][lane] = wv;
+                }
+                if (cu.rb == 0 && (bp.x == 0.f || bp.y == 0.f)) {
+                    // initialise the bandpass from this segment's mean (:406-411, :444-461), per stream
+                    const size_t wseg = (size_t)cu.seg * R;
+                    if (bp.x == 0.f) {
+                        const float *p = inA[0] + (size_t)cu.seg * seg_stride;
+                        float b = bp.x;
+                        for (int t = 0; t < R; ++t) b += p[(size_t)t * PB_NCHANOUT];
+                        bp.x = b / (float)R;
+                    }
+                    if (bp.y == 0.f) {
+                        const float *p = inA[1] + (size_t)cu.seg * seg_stride;
+                        float b = bp.y;
+                        int good = 0;
+                        for (int t = 0; t < R; ++t) {
+                            if (wrow[wseg + t] == 0.f) continue;
+                            good++;
+                            b += p[(size_t)t * PB_NCHANOUT];
+                        }
+                        bp.y = good == 0 ? 1.f : b / (float)good;
+                    }
+                }
+                s_u0[buf][lane] = bp;
+                // two batches of eight rows: sixteen (raw, excised) pairs at once would not leave 56 registers
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    d3f2 P[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        P[j].x = s_p[slot][0][hb * 8 + j][lane];
+                        P[j].y = s_p[slot][1][hb * 8 + j][lane];
+                    }
+                    d3f2 sp = sc2 * P[0];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        // raw: bp = s p + (1-s) bp (:419).  excised: the same unless p > 11 bp (:490), then bp stays
+                        const d3f2 t = om2 * bp;
+                        const float lim = bp.y * 11.f;
+                        d3f2 n = sp + t;
+                        if (j + 1 < 8) sp = sc2 * P[j + 1];
+                        n.y = P[j].y > lim ? bp.y : n.y;
+                        bp = n;
+                        s_u[buf][hb * 8 + j][lane] = bp;
+                    }
+                }
+                cu.next(cps);
+            }
+            step_barrier_raw();
+        }
+        *bpp0 = bp.x;
+        *bpp1 = bp.y;
+    } else {
+        // ---- B.  wave -> (chunk parity, 8-row group, stream); lane -> (half of the group's rows, channel), both pols
+        const int par = bi >> 2, g = (bi >> 1) & 1, stream = bi & 1;
+        const int half = lane >> 5, ch = lane & 31;
+        const int cB = cg * 32 + ch;
+        uint8_t *codes = a.codes + ((size_t)ant * 2 + stream) * a.S * a.trim;
+        float *ave = a.ave ? a.ave + ((size_t)ant * 2 + stream) * a.S * a.ave_per_seg : nullptr;
+        if (a.ave_target && ant == 0 && stream == a.target_stream) ave = a.ave_target;
+        B3State<NPOL> bs;
+        Cursor<DEPTH> cu;
+        cu.init(0, cps);
+        if (par) cu.next(cps);
+        auto take = [&](int c1, auto kur_tag) {
+            constexpr bool KUR = decltype(kur_tag)::value;
+            const int slot = cu.slot, ub = c1 & 1;
+            const int r0 = g * 8 + half * 4;
+#pragma unroll
+            for (int pol = 0; pol < 2; ++pol) {
+                const int col = pol * 32 + ch;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bs.p[pol][j] = s_p[slot][KUR ? 1 : 0][r0 + j][col];
+                    const d3f2 uu = s_u[ub][r0 + j][col];
+                    bs.u[pol][j] = KUR ? uu.y : uu.x;
+                }
+                const d3f2 up = r0 == 0 ? s_u0[ub][col] : s_u[ub][r0 ? r0 - 1 : 0][col];
+                bs.uprev[pol] = KUR ? up.y : up.x;
+            }
+            bs.wt_sum = 0;
+            bs.wt_sumf = 0.f;
+            if (KUR) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bs.w[j] = s_w[c1 % 3][r0 + j];
+                // the group's weight sums run over all eight rows in order; the weights are the same in every lane
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const float w = s_w[c1 % 3][g * 8 + jj];
+                    const bool ok = NPOL == 1 ? (w >= 0.2f) : !(w < 0.2f);
+                    bs.wt_sum += ok ? 1 : 0;
+                    bs.wt_sumf += ok ? w : 0.f;
+                }
+            }
+            bs.trow = cu.rb * NG + g;
+            bs.seg = cu.seg;
+            d3_rows<NPOL, KUR>(bs, 0);
+        };
+        auto finish = [&](auto kur_tag) {
+            constexpr bool KUR = decltype(kur_tag)::value;
+            d3_rows<NPOL, KUR>(bs, 2);
+            float accv[2];
+#pragma unroll
+            for (int o = 0; o < NPOL; ++o) {
+                // half 0: ((((+0 + t0) + t1) + t2) + t3; half 1 goes on from its partner's sum with its own four terms
+                const float part = (((0.f + bs.term[o][0]) + bs.term[o][1]) + bs.term[o][2]) + bs.term[o][3];
+                const float got = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, part)));
+                accv[o] = (((got + bs.term[o][0]) + bs.term[o][1]) + bs.term[o][2]) + bs.term[o][3];
+            }
+            if (NPOL == 1) accv[1] = 0.f;
+            if (!KUR) {
+                accv[0] *= a.tscale;
+                accv[1] *= a.tscale;
+            } else {
+                const bool ok = (bs.wt_sumf / PB_NSCRUNCH) >= 0.2f;
+                const float d = sqrtf((float)bs.wt_sum);
+                const float q0 = accv[0] / d, q1 = accv[1] / d;
+                accv[0] = ok ? q0 : 0.f;
+                accv[1] = ok ? q1 : 0.f;
+            }
+            uint8_t *cseg = codes + (size_t)bs.seg * a.trim;
+            float *aseg = ave ? ave + (size_t)bs.seg * a.ave_per_seg : nullptr;
+            const int trow = bs.trow;
+#pragma unroll
+            for (int pol = 0; pol < NPOL; ++pol) {
+                const float acc = pol ? accv[1] : accv[0];
+                const size_t n = (NPOL == 1) ? (size_t)trow * PB_NCHANOUT + cB : ((size_t)trow * 2 + pol) * PB_NCHANOUT + cB;
+                if (aseg && half) aseg[(NPOL == 1) ? n : ((size_t)pol * ntime + trow) * PB_NCHANOUT + cB] = acc;
+                const unsigned q = quantise<NBIT>(acc);
+                if (NBIT == 8) {
+                    if (half) cseg[n] = (uint8_t)q;
+                } else if (NBIT == 4) {
+                    const unsigned hi = __shfl_down(q, 1);
+                    if (half && !(lane & 1)) cseg[n >> 1] = (uint8_t)(q | (hi << 4));
+                } else {
+                    const unsigned q1 = __shfl_down(q, 1);
+                    const unsigned q2 = __shfl_down(q, 2);
+                    const unsigned q3 = __shfl_down(q, 3);
+                    if (half && !(lane & 3)) cseg[n >> 2] = (uint8_t)(q | (q1 << 2) | (q2 << 4) | (q3 << 6));
+                }
+            }
+        };
+        step_barrier_raw();
+        for (int k = 0; k < nstep; ++k) {
+            const int c1 = k - 1;
+            if (c1 >= 0 && (c1 & 1) == par) {
+                if (c1 < nchunk) {
+                    if (stream) take(c1, std::true_type());
+                    else take(c1, std::false_type());
+                }
+            } else if (c1 >= 1) {
+                if (c1 - 1 < nchunk) {
+                    if (stream) finish(std::true_type());
+                    else finish(std::false_type());
+                }
+                cu.next(cps);
+                cu.next(cps);
+            }
+            step_barrier_raw();
+        }
+    }
+}
+
+template <int NPOL, int DEPTH>
+static void launch_d3(const Detect2Args &a, int nbit, dim3 grid, hipStream_t st)
+{
+    if (nbit == 8) k_detect3<NPOL, 8, DEPTH><<<grid, D3_THREADS, 0, st>>>(a);
+    else if (nbit == 4) k_detect3<NPOL, 4, DEPTH><<<grid, D3_THREADS, 0, st>>>(a);
+    else k_detect3<NPOL, 2, DEPTH><<<grid, D3_THREADS, 0, st>>>(a);
+}
+
 template <int T, int DEPTH>
 static void launch_all(const Detect2Args &a, int mode, int npol, int nbit, dim3 grid, hipStream_t st)
 {
@@ -618,8 +963,21 @@ hipError_t launch_detect_pow(pb_handle *h, int nseg)
     a.oms = 1 - a.scale;
     a.tscale = (float)sqrt(1. / PB_NSCRUNCH);
     dim3 grid(PB_NCHANOUT / 32, h->cfg.rfi_mode == 2 ? 2 : 1, h->A);
+#if defined(D2_ABL) && (D2_ABL & 2)
+    grid.y = 1;      // (timing experiment, RESULTS INVALID: only the raw stream's 128 workgroups -- what the step would be
+                     //  with half of detect's workgroups at their present lifetime, the bound of a two-stream workgroup)
+#endif
     // three chunks in flight where detect runs wholly beside the next batch's channeliser (it flags its own rows and
     // starts straight behind the previous one), two otherwise (measured both ways, see the comment on DEPTH)
+#if PB_DETECT3
+    if (h->cfg.rfi_mode == 2 && h->R % D3_T == 0) {
+        // both streams in one workgroup: 128 workgroups of ten waves (k_detect3)
+        dim3 g3(PB_NCHANOUT / 32, 1, h->A);
+        if (h->cfg.npol == 1) launch_d3<1, 3>(a, h->cfg.nbit, g3, h->stream);
+        else launch_d3<2, 3>(a, h->cfg.nbit, g3, h->stream);
+        return hipGetLastError();
+    }
+#endif
     const int depth_env = h->sched.detect_depth;     // PB_DETECT_DEPTH 2 / 3: timing experiments
     const bool deep = depth_env ? depth_env == 3
                                 : (D2_DEPTH_OVERLAPPED == 3 && pb_fused_kurtosis(h) && h->cfg.taps == 1 && h->sets.size() >= 2 && h->A == 1);
