@@ -84,7 +84,7 @@ struct Detect2Args {
 #ifdef D2_STAMP
 // timing experiments (variant builds only): per wave of one workgroup, cycles spent working / waiting at the
 // step barrier; read back with pb_internal_d2_stamps
-__device__ unsigned long long g_d2_stamp[8][4];
+__device__ unsigned long long g_d2_stamp[16][4];
 extern "C" int pb_internal_d2_stamps(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_d2_stamp), sizeof(g_d2_stamp));
@@ -594,20 +594,26 @@ static void launch_mode(const Detect2Args &a, int mode, dim3 grid, hipStream_t s
 // all the work and halves the slots: one workgroup = 32 channels x 2 pols x BOTH streams, ten waves (the registers a
 // displaced channeliser workgroup frees on a CU hold them: <= 56 VGPRs each, three per SIMD beside two channeliser
 // workgroups), chunks of 16 rows, one barrier per chunk step:
-//   loader (wave 6): LDS-DMA of the chunk's 2 x 16 rows x 64 columns into a ring slot, DEPTH chunks ahead;
+//   loader (wave 6): LDS-DMA of the chunk's 2 x 16 rows x 64 columns into a ring slot, DEPTH chunks ahead.  A workgroup
+//      now streams twice the bytes per unit time, so it needs twice the bytes in flight to cover the same memory
+//      latency: 5 chunks x 8 KB where k_detect2 has 3 x 8 KB (with three the step simply became latency / 3 and the
+//      workgroup lived twice as long: profiles/r06_notes.md).  The LDS for that comes from NOT exporting bp per row:
 //   A  (wave 2; lane = (pol, channel)): BOTH recurrences side by side in packed registers (raw, excised): per row one
-//      packed multiply (1-s) bp, one packed multiply s p (of the next row), one packed add, and the excised half's clip
-//      test (11 bp, compare, select) -- the same IEEE operations on the same operands as k_detect2's two recurrence
-//      waves, hence the same bits; bp after every row goes to LDS as one 8-byte store (raw, excised);
+//      packed multiply (1-s) bp, one packed multiply s p, one packed add, and the excised half's clip test (11 bp,
+//      compare, select) -- the same IEEE operations on the same operands as k_detect2's two recurrence waves, hence the
+//      same bits.  It leaves bp in LDS only at the chunk's start and after rows 3, 7, 11 (one 8-byte store each);
 //   B  (the other eight waves): wave -> (chunk parity, 8-row group, stream), lane -> (half of the group's rows, channel),
-//      both pols.  Everything that only needs (p, bp) of its own rows as in k_detect2 -- clip test again, division, pol
-//      scrunch in double, weighted time scrunch, quantiser.  The 8-row time scrunch is a SEQUENTIAL fp32 sum over the
-//      rows: lanes of half 0 sum rows 0-3 from +0.0, hand the partial sum to their partner lane (half 1, lane + 32),
-//      which adds its four terms on top in order and finishes -- the same additions in the same order as one lane
-//      walking eight rows.  A B wave takes chunk c into registers at step c+1 (rows 0-1 of its half) and finishes it at
-//      step c+2, while the waves of the other parity take chunk c+1.
-// LDS: ring (DEPTH + 2) x 8 KB + 16 KB of bp + 1.2 KB = 58.6 KB at DEPTH 3: the same 46 allocation granules of 1 280 B
-// as k_detect2's three-chunk ring (tools/lds_granule.hip measures the granule).
+//      both pols.  A lane RE-RUNS the recurrence over its own four rows from the exported bp before them -- the same
+//      three (raw) or five (excised) operations per row that A performs, so the same bits -- and with bp before and
+//      after each row does what k_detect2's phase B does: clip test, division, pol scrunch in double, weighted time
+//      scrunch, quantiser.  The 8-row time scrunch is a SEQUENTIAL fp32 sum over the rows: lanes of half 0 sum rows
+//      0-3 from +0.0, hand the partial sum to their partner lane (half 1, lane + 32), which adds its four terms on top
+//      in order and finishes -- the same additions in the same order as one lane walking eight rows.
+//      A B wave reads the powers of chunk c while A works on it (step c; the ring slot is free again after that step),
+//      takes bp and the weights at step c+1 (rows 0-1 of its half) and finishes at step c+2, when it also reads the
+//      powers of chunk c+2; the waves of the other parity do the same one step later.
+// LDS: ring (DEPTH + 1) x 8 KB + 5 KB of bp + 0.2 KB = 54.5 KB at DEPTH 5: 43 allocation granules of 1 280 B (k_detect2's
+// three-chunk ring: 46; tools/lds_granule.hip measures the granule), beside two channeliser workgroups of 40.
 // Used for RFI mode 2 when rows_per_seg is a multiple of 16; everything else stays with k_detect2.
 #ifndef PB_DETECT3
 #define PB_DETECT3 0            // 1: launch_detect_pow takes this kernel where it applies
@@ -618,6 +624,9 @@ static void launch_mode(const Detect2Args &a, int mode, dim3 grid, hipStream_t s
 #define D3_WAVE_L 6
 #ifndef D3_VGPRS
 #define D3_VGPRS 56
+#endif
+#ifndef D3_DEPTH
+#define D3_DEPTH 5
 #endif
 
 namespace {
@@ -631,16 +640,18 @@ __device__ __forceinline__ int d3_b_index(int wave)
 }
 
 template <int NPOL> struct B3State {
-    float p[2][4], u[2][4], uprev[2];
+    float p[2][4];                 // powers of the lane's four rows, per pol (read one step ahead)
+    float pn[2][4];                // ... of the wave's NEXT chunk
+    float ub[2];                   // bp before the row that comes next, per pol
     float w[4];                    // weights of this lane's four rows (excised stream)
     float term[2][4];              // what each row adds to the time scrunch (per output pol)
     float wt_sumf;
     int wt_sum, trow, seg;
 };
 
-// rows j0, j0 + 1 of the lane's four
+// rows j0, j0 + 1 of the lane's four: the recurrence again (bp before -> bp after), then phase B of k_detect2
 template <int NPOL, bool KUR>
-__device__ __forceinline__ void d3_rows(B3State<NPOL> &s, int j0)
+__device__ __forceinline__ void d3_rows(B3State<NPOL> &s, int j0, float scale, float oms)
 {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
@@ -649,12 +660,17 @@ __device__ __forceinline__ void d3_rows(B3State<NPOL> &s, int j0)
         const float w = KUR ? s.w[j] : 1.f;
 #pragma unroll
         for (int pol = 0; pol < 2; ++pol) {
-            const float un = s.u[pol][j];
-            const float ub = j == 0 ? s.uprev[pol] : s.u[pol][j ? j - 1 : 0];
             const float p = s.p[pol][j];
+            const float ub = s.ub[pol];
+            // A's operations on A's operands: s p + (1-s) bp (:419, :499); excised: unless p > 11 bp (:490)
+            const float sp = scale * p, t = oms * ub;
+            float un = sp + t;
+            const bool clip = KUR && p > ub * 11.f;
+            if (KUR) un = clip ? ub : un;
+            s.ub[pol] = un;
             float v = p / un - 1.f;
             if (KUR) {
-                v = p > ub * 11.f ? 10.f : v;          // the recurrence wave's own test (:490-491): clipped -> 10
+                v = clip ? 10.f : v;                   // clipped -> 10 (:490-491)
                 v = w == 0.f ? 0.f : v;                // :474-476
             }
             x[pol] = v;
@@ -688,10 +704,10 @@ __device__ __forceinline__ void d3_rows(B3State<NPOL> &s, int j0)
 template <int NPOL, int NBIT, int DEPTH>
 __global__ __launch_bounds__(D3_THREADS) __attribute__((amdgpu_num_vgpr(D3_VGPRS))) void k_detect3(Detect2Args a)
 {
-    constexpr int T = D3_T, NG = T / PB_NSCRUNCH, LPC = 2 * (T / 4);
-    __shared__ __attribute__((aligned(16))) float s_p[D2_NSLOT][2][T][64];     // [slot][stream][row][pol * 32 + channel]
-    __shared__ __attribute__((aligned(16))) d3f2 s_u[2][T][64];                // bp after each row: (raw, excised)
-    __shared__ d3f2 s_u0[2][64];                                               // bp before the chunk's first row
+    constexpr int T = D3_T, NG = T / PB_NSCRUNCH, LPC = 2 * (T / 4), NSLOT = DEPTH + 1;
+    static_assert((DEPTH - 1) * LPC < 64, "vmcnt is six bits");
+    __shared__ __attribute__((aligned(16))) float s_p[NSLOT][2][T][64];        // [slot][stream][row][pol * 32 + channel]
+    __shared__ __attribute__((aligned(16))) d3f2 s_ue[2][4][64];               // bp (raw, excised) before rows 0, 4, 8, 12
     __shared__ float s_w[3][T];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int cg = blockIdx.x, ant = blockIdx.z;
@@ -701,42 +717,68 @@ __global__ __launch_bounds__(D3_THREADS) __attribute__((amdgpu_num_vgpr(D3_VGPRS
     const size_t pol_stride = (size_t)R * PB_NCHANOUT, seg_stride = 2 * pol_stride;
     const float *Pant[2] = {a.P[0] + (size_t)ant * a.S * seg_stride, a.P[1] + (size_t)ant * a.S * seg_stride};
     const int bi = d3_b_index(wave);
+#ifdef D2_STAMP
+    StepClock clk;
+#define d3_barrier() step_barrier_clk(clk)
+#else
+#define d3_barrier() step_barrier_raw()
+#endif
+    // position in the stream of chunks (the ring has its own modulus here: NSLOT = DEPTH + 1)
+    struct Cur {
+        int c, slot, seg, rb;
+        __device__ __forceinline__ void init(int cps_) { c = 0; slot = 0; seg = 0; rb = 0; (void)cps_; }
+        __device__ __forceinline__ void next(int cps_)
+        {
+            slot = slot + 1 == NSLOT ? 0 : slot + 1;
+            rb = rb + 1;
+            if (rb == cps_) { rb = 0; seg = seg + 1; }
+            c = c + 1;
+        }
+    };
 
     if (wave == D3_WAVE_L) {
         // ---- loader: lane -> (row in group of 4, pol, 4 channels); one instruction = 4 rows x 64 columns of one stream
         const int ld_row = lane >> 4, ld_pol = (lane >> 3) & 1, ld_c = cg * 32 + (lane & 7) * 4;
         const size_t loff = (size_t)ld_pol * pol_stride + (size_t)ld_row * PB_NCHANOUT + ld_c;
-        auto issue = [&](const Cursor<DEPTH> &cu) {
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const float *src = Pant[st] + (size_t)cu.seg * seg_stride + (size_t)(cu.rb * T) * PB_NCHANOUT + loff;
-#pragma unroll
-                for (int i = 0; i < T / 4; ++i)
-                    __builtin_amdgcn_global_load_lds(
-                        (const void __attribute__((address_space(1))) *)(src + (size_t)(4 * i) * PB_NCHANOUT),
-                        (void __attribute__((address_space(3))) *)&s_p[cu.slot][st][4 * i][0], 16, 0, D2_LOAD_AUX);
-            }
-        };
-        auto wait_chunks = [&](int n) {
-            if (n <= 0) wait_vmcnt<0>();
-            else if (n == 1) wait_vmcnt<LPC>();
-            else wait_vmcnt<(DEPTH - 1) * LPC>();           // (DEPTH <= 3: n == 2)
-        };
-        Cursor<DEPTH> cu;
-        cu.init(0, cps);
-        auto fill = [&](int upto) {
+        Cur cu;
+        cu.init(cps);
+        auto fill = [&](int upto) {       // request chunks < upto
             while (cu.c < nchunk && cu.c < upto) {
-                issue(cu);
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const float *src = Pant[st] + (size_t)cu.seg * seg_stride + (size_t)(cu.rb * T) * PB_NCHANOUT + loff;
+#pragma unroll
+                    for (int i = 0; i < T / 4; ++i)
+                        __builtin_amdgcn_global_load_lds(
+                            (const void __attribute__((address_space(1))) *)(src + (size_t)(4 * i) * PB_NCHANOUT),
+                            (void __attribute__((address_space(3))) *)&s_p[cu.slot][st][4 * i][0], 16, 0, D2_LOAD_AUX);
+                }
                 cu.next(cps);
             }
         };
+        // at most n chunks' loads still in flight (LPC loads each, n <= DEPTH - 1)
+        auto wait_chunks = [&](int n) {
+            if (n <= 0) wait_vmcnt<0>();
+            else if (n == 1) wait_vmcnt<LPC>();
+            else if (n == 2) wait_vmcnt<(DEPTH >= 3 ? 2 : 1) * LPC>();
+            else if (n == 3) wait_vmcnt<(DEPTH >= 4 ? 3 : 1) * LPC>();
+            else wait_vmcnt<(DEPTH - 1) * LPC>();
+        };
+        // step k: A and the B waves of parity k read chunk k's slot; chunk k + DEPTH goes into the slot chunk k - 1 had
+        // (read in step k - 1): DEPTH chunks beyond the one being read are requested
         fill(DEPTH);
         wait_chunks(cu.c - 1);                       // chunk 0 has landed
-        step_barrier_raw();
+        d3_barrier();
         for (int k = 0; k < nstep; ++k) {
-            fill(k + 1 + DEPTH);
+            fill(k + DEPTH + 1);
+#ifdef D2_STAMP
+            const long long tw0 = D2_NOW();
+#endif
             wait_chunks(cu.c - (k + 2));             // chunk k + 1 has landed
-            step_barrier_raw();
+#ifdef D2_STAMP
+            clk.extra += D2_NOW() - tw0;
+#endif
+            d3_barrier();
         }
     } else if (wave == D3_WAVE_A) {
         // ---- A: both recurrences.  lane -> (pol, channel); registers carry (raw, excised) pairs
@@ -747,9 +789,9 @@ __global__ __launch_bounds__(D3_THREADS) __attribute__((amdgpu_num_vgpr(D3_VGPRS
         float *bpp1 = a.bp + (((size_t)ant * 2 + 1) * 2 + polA) * PB_NCHANOUT + cA;
         d3f2 bp = {*bpp0, *bpp1};
         const d3f2 sc2 = {a.scale, a.scale}, om2 = {a.oms, a.oms};
-        Cursor<DEPTH> cu;
-        cu.init(0, cps);
-        step_barrier_raw();
+        Cur cu;
+        cu.init(cps);
+        d3_barrier();
         float wv_next = (lane < T && nchunk > 0) ? wrow[lane] : 1.f;
         for (int k = 0; k < nstep; ++k) {
             if (k < nchunk) {
@@ -780,7 +822,6 @@ __global__ __launch_bounds__(D3_THREADS) __attribute__((amdgpu_num_vgpr(D3_VGPRS
                         bp.y = good == 0 ? 1.f : b / (float)good;
                     }
                 }
-                s_u0[buf][lane] = bp;
                 // two batches of eight rows: sixteen (raw, excised) pairs at once would not leave 56 registers
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
@@ -790,22 +831,21 @@ __global__ __launch_bounds__(D3_THREADS) __attribute__((amdgpu_num_vgpr(D3_VGPRS
                         P[j].x = s_p[slot][0][hb * 8 + j][lane];
                         P[j].y = s_p[slot][1][hb * 8 + j][lane];
                     }
-                    d3f2 sp = sc2 * P[0];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
+                        if ((j & 3) == 0) s_ue[buf][hb * 2 + (j >> 2)][lane] = bp;      // bp before rows 0, 4, 8, 12
                         // raw: bp = s p + (1-s) bp (:419).  excised: the same unless p > 11 bp (:490), then bp stays
+                        const d3f2 sp = sc2 * P[j];
                         const d3f2 t = om2 * bp;
                         const float lim = bp.y * 11.f;
                         d3f2 n = sp + t;
-                        if (j + 1 < 8) sp = sc2 * P[j + 1];
                         n.y = P[j].y > lim ? bp.y : n.y;
                         bp = n;
-                        s_u[buf][hb * 8 + j][lane] = bp;
                     }
                 }
                 cu.next(cps);
             }
-            step_barrier_raw();
+            d3_barrier();
         }
         *bpp0 = bp.x;
         *bpp1 = bp.y;
@@ -814,28 +854,31 @@ __global__ __launch_bounds__(D3_THREADS) __attribute__((amdgpu_num_vgpr(D3_VGPRS
         const int par = bi >> 2, g = (bi >> 1) & 1, stream = bi & 1;
         const int half = lane >> 5, ch = lane & 31;
         const int cB = cg * 32 + ch;
+        const int r0 = g * 8 + half * 4;
+        const float scale = a.scale, oms = a.oms;
         uint8_t *codes = a.codes + ((size_t)ant * 2 + stream) * a.S * a.trim;
         float *ave = a.ave ? a.ave + ((size_t)ant * 2 + stream) * a.S * a.ave_per_seg : nullptr;
         if (a.ave_target && ant == 0 && stream == a.target_stream) ave = a.ave_target;
         B3State<NPOL> bs;
-        Cursor<DEPTH> cu;
-        cu.init(0, cps);
+        Cur cu;                          // this wave's next chunk: those of its parity
+        cu.init(cps);
         if (par) cu.next(cps);
+        // the powers of the wave's next chunk (cu), read while A works on that chunk
+        auto preload = [&]() {
+#pragma unroll
+            for (int pol = 0; pol < 2; ++pol)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bs.pn[pol][j] = s_p[cu.slot][stream][r0 + j][pol * 32 + ch];
+        };
         auto take = [&](int c1, auto kur_tag) {
             constexpr bool KUR = decltype(kur_tag)::value;
-            const int slot = cu.slot, ub = c1 & 1;
-            const int r0 = g * 8 + half * 4;
+            const int ub = c1 & 1;
 #pragma unroll
             for (int pol = 0; pol < 2; ++pol) {
-                const int col = pol * 32 + ch;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    bs.p[pol][j] = s_p[slot][KUR ? 1 : 0][r0 + j][col];
-                    const d3f2 uu = s_u[ub][r0 + j][col];
-                    bs.u[pol][j] = KUR ? uu.y : uu.x;
-                }
-                const d3f2 up = r0 == 0 ? s_u0[ub][col] : s_u[ub][r0 ? r0 - 1 : 0][col];
-                bs.uprev[pol] = KUR ? up.y : up.x;
+                for (int j = 0; j < 4; ++j) bs.p[pol][j] = bs.pn[pol][j];
+                const d3f2 up = s_ue[ub][r0 >> 2][pol * 32 + ch];
+                bs.ub[pol] = KUR ? up.y : up.x;
             }
             bs.wt_sum = 0;
             bs.wt_sumf = 0.f;
@@ -853,11 +896,11 @@ __global__ __launch_bounds__(D3_THREADS) __attribute__((amdgpu_num_vgpr(D3_VGPRS
             }
             bs.trow = cu.rb * NG + g;
             bs.seg = cu.seg;
-            d3_rows<NPOL, KUR>(bs, 0);
+            d3_rows<NPOL, KUR>(bs, 0, scale, oms);
         };
         auto finish = [&](auto kur_tag) {
             constexpr bool KUR = decltype(kur_tag)::value;
-            d3_rows<NPOL, KUR>(bs, 2);
+            d3_rows<NPOL, KUR>(bs, 2, scale, oms);
             float accv[2];
 #pragma unroll
             for (int o = 0; o < NPOL; ++o) {
@@ -899,25 +942,37 @@ __global__ __launch_bounds__(D3_THREADS) __attribute__((amdgpu_num_vgpr(D3_VGPRS
                 }
             }
         };
-        step_barrier_raw();
+        d3_barrier();
         for (int k = 0; k < nstep; ++k) {
-            const int c1 = k - 1;
-            if (c1 >= 0 && (c1 & 1) == par) {
-                if (c1 < nchunk) {
-                    if (stream) take(c1, std::true_type());
-                    else take(c1, std::false_type());
-                }
-            } else if (c1 >= 1) {
-                if (c1 - 1 < nchunk) {
+            // step k: chunks of this wave's parity: read the powers of chunk k (A works on it now), or take chunk k - 1
+            // (bp exports and weights are there since the last barrier) and do rows 0-1; the other steps finish the
+            // chunk taken one step before
+            if ((k & 1) == par) {
+                if (k >= 2 && k - 2 < nchunk) {
                     if (stream) finish(std::true_type());
                     else finish(std::false_type());
                 }
-                cu.next(cps);
-                cu.next(cps);
+                if (k >= 2) {
+                    cu.next(cps);
+                    cu.next(cps);
+                }
+                if (k < nchunk) preload();             // cu is chunk k now
+            } else if (k >= 1 && k - 1 < nchunk) {
+                if (stream) take(k - 1, std::true_type());
+                else take(k - 1, std::false_type());
             }
-            step_barrier_raw();
+            d3_barrier();
         }
     }
+#ifdef D2_STAMP
+    if (blockIdx.x == 17 && blockIdx.z == 0 && lane == 0) {
+        g_d2_stamp[wave & 15][0] += (unsigned long long)clk.work;
+        g_d2_stamp[wave & 15][1] += (unsigned long long)clk.wait;
+        g_d2_stamp[wave & 15][2] += (unsigned long long)clk.extra;
+        g_d2_stamp[wave & 15][3] += 1ull;
+    }
+#endif
+#undef d3_barrier
 }
 
 template <int NPOL, int DEPTH>
@@ -973,8 +1028,8 @@ hipError_t launch_detect_pow(pb_handle *h, int nseg)
     if (h->cfg.rfi_mode == 2 && h->R % D3_T == 0) {
         // both streams in one workgroup: 128 workgroups of ten waves (k_detect3)
         dim3 g3(PB_NCHANOUT / 32, 1, h->A);
-        if (h->cfg.npol == 1) launch_d3<1, 3>(a, h->cfg.nbit, g3, h->stream);
-        else launch_d3<2, 3>(a, h->cfg.nbit, g3, h->stream);
+        if (h->cfg.npol == 1) launch_d3<1, D3_DEPTH>(a, h->cfg.nbit, g3, h->stream);
+        else launch_d3<2, D3_DEPTH>(a, h->cfg.nbit, g3, h->stream);
         return hipGetLastError();
     }
 #endif
