@@ -27,7 +27,7 @@ for st in range(NSETS):
         h.submit_planar_dev(0, s, sec[s][0].data_ptr(), sec[s][1].data_ptr(), h.seg_samples)
 h.sync()
 def stamps():
-    o = (C.c_ulonglong * 64)()
+    o = (C.c_ulonglong * 32)()
     rc = L.pb_internal_d2_stamps(o)
     assert rc == 0
     return list(o)
@@ -55,12 +55,7 @@ nl = max(1, out[3])
 names = {0: "A", int(os.environ.get("D2_WAVE_L", "5")): "L", 1: "B0", 2: "B1", 3: "B2", 9 - int(os.environ.get("D2_WAVE_L", "5")): "B3"}
 nstep = 10 * 1024 // 32 + 2
 print("rc", rc, "steps", nstep, "launches", nl, "pipelined" if PIPE else "alone")
-D3 = os.environ.get("D3") == "1"          # the library under test launches k_detect3 (ten waves, 16-row steps)
-if D3:
-    names = {2: "A", 6: "L", 0: "B0", 1: "B1", 3: "B2", 4: "B3", 5: "B4", 7: "B5", 8: "B6", 9: "B7"}
-    nstep = 10 * 1024 // 16 + 2
-    print("k_detect3: steps", nstep)
-for w in range(10 if D3 else 6):
+for w in range(6):
     work, wait, extra = out[w * 4] / nl, out[w * 4 + 1] / nl, out[w * 4 + 2] / nl
     print("wave %d %-3s work %8d (%6.0f/step)  barrier wait %8d (%6.0f/step)  dma wait %8d (%6.0f/step)"
           % (w, names.get(w, "?"), work, work / nstep, wait, wait / nstep, extra, extra / nstep))

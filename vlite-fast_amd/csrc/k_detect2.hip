@@ -37,7 +37,6 @@
 //
 // HBM traffic: the power planes (4 B per row x channel x pol x stream) once; outputs 1/64 of it.
 #include <cstdlib>
-#include <type_traits>
 
 #include "pb_internal.h"
 
@@ -84,7 +83,7 @@ struct Detect2Args {
 #ifdef D2_STAMP
 // timing experiments (variant builds only): per wave of one workgroup, cycles spent working / waiting at the
 // step barrier; read back with pb_internal_d2_stamps
-__device__ unsigned long long g_d2_stamp[16][4];
+__device__ unsigned long long g_d2_stamp[8][4];
 extern "C" int pb_internal_d2_stamps(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_d2_stamp), sizeof(g_d2_stamp));
@@ -584,405 +583,6 @@ static void launch_mode(const Detect2Args &a, int mode, dim3 grid, hipStream_t s
     else k_detect2<T, NPOL, NBIT, 2, DEPTH><<<grid, D2_THREADS, 0, st>>>(a);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// k_detect3 (round 6): BOTH streams in one workgroup, so that a launch is 128 workgroups instead of 256.
-//
-// Why: what bounds the pipelined step is how many workgroups a CU holds (profiles/r05_notes.md section 1): a detect
-// workgroup of either form takes the place of one 50-KB channeliser workgroup on its CU for as long as it lives.
-// k_detect2 is one workgroup per (32 channels, stream): 256 x 0.24 ms of such slots per second of data.  With half of
-// them left out (timing experiment, results invalid) the step is 14 % shorter (profiles/r06_notes.md).  This kernel keeps
-// all the work and halves the slots: one workgroup = 32 channels x 2 pols x BOTH streams, ten waves (the registers a
-// displaced channeliser workgroup frees on a CU hold them: <= 56 VGPRs each, three per SIMD beside two channeliser
-// workgroups), chunks of 16 rows, one barrier per chunk step:
-//   loader (wave 6): LDS-DMA of the chunk's 2 x 16 rows x 64 columns into a ring slot, DEPTH chunks ahead.  A workgroup
-//      now streams twice the bytes per unit time, so it needs twice the bytes in flight to cover the same memory
-//      latency: 5 chunks x 8 KB where k_detect2 has 3 x 8 KB (with three the step simply became latency / 3 and the
-//      workgroup lived twice as long: profiles/r06_notes.md).  The LDS for that comes from NOT exporting bp per row:
-//   A  (wave 2; lane = (pol, channel)): BOTH recurrences side by side in packed registers (raw, excised): per row one
-//      packed multiply (1-s) bp, one packed multiply s p, one packed add, and the excised half's clip test (11 bp,
-//      compare, select) -- the same IEEE operations on the same operands as k_detect2's two recurrence waves, hence the
-//      same bits.  It leaves bp in LDS only at the chunk's start and after rows 3, 7, 11 (one 8-byte store each);
-//   B  (the other eight waves): wave -> (chunk parity, 8-row group, stream), lane -> (half of the group's rows, channel),
-//      both pols.  A lane RE-RUNS the recurrence over its own four rows from the exported bp before them -- the same
-//      three (raw) or five (excised) operations per row that A performs, so the same bits -- and with bp before and
-//      after each row does what k_detect2's phase B does: clip test, division, pol scrunch in double, weighted time
-//      scrunch, quantiser.  The 8-row time scrunch is a SEQUENTIAL fp32 sum over the rows: lanes of half 0 sum rows
-//      0-3 from +0.0, hand the partial sum to their partner lane (half 1, lane + 32), which adds its four terms on top
-//      in order and finishes -- the same additions in the same order as one lane walking eight rows.
-//      A B wave reads the powers of chunk c while A works on it (step c; the ring slot is free again after that step),
-//      takes bp and the weights at step c+1 (rows 0-1 of its half) and finishes at step c+2, when it also reads the
-//      powers of chunk c+2; the waves of the other parity do the same one step later.
-// LDS: ring (DEPTH + 1) x 8 KB + 5 KB of bp + 0.2 KB = 54.5 KB at DEPTH 5: 43 allocation granules of 1 280 B (k_detect2's
-// three-chunk ring: 46; tools/lds_granule.hip measures the granule), beside two channeliser workgroups of 40.
-// Used for RFI mode 2 when rows_per_seg is a multiple of 16; everything else stays with k_detect2.
-#ifndef PB_DETECT3
-#define PB_DETECT3 0            // 1: launch_detect_pow takes this kernel where it applies
-#endif
-#define D3_T 16
-#define D3_THREADS 640
-#define D3_WAVE_A 2             // waves w and w + 4 (and w + 8) share a SIMD: A and the loader get one to themselves
-#define D3_WAVE_L 6
-#ifndef D3_VGPRS
-#define D3_VGPRS 56
-#endif
-#ifndef D3_DEPTH
-#define D3_DEPTH 5
-#endif
-
-namespace {
-typedef float d3f2 __attribute__((ext_vector_type(2)));
-
-// which phase-B wave (0..7) a wave of the ten is, or -1
-__device__ __forceinline__ int d3_b_index(int wave)
-{
-    // waves 0 1 3 4 5 7 8 9 -> 0..7
-    return wave == D3_WAVE_A || wave == D3_WAVE_L ? -1 : wave - (wave > D3_WAVE_A ? 1 : 0) - (wave > D3_WAVE_L ? 1 : 0);
-}
-
-template <int NPOL> struct B3State {
-    float p[2][4];                 // powers of the lane's four rows, per pol (read one step ahead)
-    float pn[2][4];                // ... of the wave's NEXT chunk
-    float ub[2];                   // bp before the row that comes next, per pol
-    float w[4];                    // weights of this lane's four rows (excised stream)
-    float term[2][4];              // what each row adds to the time scrunch (per output pol)
-    float wt_sumf;
-    int wt_sum, trow, seg;
-};
-
-// rows j0, j0 + 1 of the lane's four: the recurrence again (bp before -> bp after), then phase B of k_detect2
-template <int NPOL, bool KUR>
-__device__ __forceinline__ void d3_rows(B3State<NPOL> &s, int j0, float scale, float oms)
-{
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int j = j0 + jj;
-        float x[2];
-        const float w = KUR ? s.w[j] : 1.f;
-#pragma unroll
-        for (int pol = 0; pol < 2; ++pol) {
-            const float p = s.p[pol][j];
-            const float ub = s.ub[pol];
-            // A's operations on A's operands: s p + (1-s) bp (:419, :499); excised: unless p > 11 bp (:490)
-            const float sp = scale * p, t = oms * ub;
-            float un = sp + t;
-            const bool clip = KUR && p > ub * 11.f;
-            if (KUR) un = clip ? ub : un;
-            s.ub[pol] = un;
-            float v = p / un - 1.f;
-            if (KUR) {
-                v = clip ? 10.f : v;                   // clipped -> 10 (:490-491)
-                v = w == 0.f ? 0.f : v;                // :474-476
-            }
-            x[pol] = v;
-        }
-        if (NPOL == 1) {
-            const float sum = x[0] + x[1];
-            const float y = (float)(M_SQRT1_2 * (double)sum);
-            if (!KUR) {
-                s.term[0][j] = y;
-            } else {
-                const bool ok = w >= 0.2f;           // MIN_WEIGHT, both pols share the row weight
-                const float prod = w * y;
-                s.term[0][j] = ok ? prod : 0.f;
-            }
-        } else {
-            if (!KUR) {
-                s.term[0][j] = x[0];
-                s.term[1][j] = x[1];
-            } else {
-                const bool ok = !(w < 0.2f);
-                const float pr0 = w * x[0], pr1 = w * x[1];
-                s.term[0][j] = ok ? pr0 : 0.f;
-                s.term[1][j] = ok ? pr1 : 0.f;
-            }
-        }
-    }
-}
-
-}  // namespace
-
-template <int NPOL, int NBIT, int DEPTH>
-__global__ __launch_bounds__(D3_THREADS) __attribute__((amdgpu_num_vgpr(D3_VGPRS))) void k_detect3(Detect2Args a)
-{
-    constexpr int T = D3_T, NG = T / PB_NSCRUNCH, LPC = 2 * (T / 4), NSLOT = DEPTH + 1;
-    static_assert((DEPTH - 1) * LPC < 64, "vmcnt is six bits");
-    __shared__ __attribute__((aligned(16))) float s_p[NSLOT][2][T][64];        // [slot][stream][row][pol * 32 + channel]
-    __shared__ __attribute__((aligned(16))) d3f2 s_ue[2][4][64];               // bp (raw, excised) before rows 0, 4, 8, 12
-    __shared__ float s_w[3][T];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int cg = blockIdx.x, ant = blockIdx.z;
-    const int R = a.R, cps = R / T, nchunk = a.nseg * cps, nstep = nchunk + 2;
-    const int ntime = R / PB_NSCRUNCH;
-    const float *wrow = a.wrow + (size_t)ant * a.S * R;
-    const size_t pol_stride = (size_t)R * PB_NCHANOUT, seg_stride = 2 * pol_stride;
-    const float *Pant[2] = {a.P[0] + (size_t)ant * a.S * seg_stride, a.P[1] + (size_t)ant * a.S * seg_stride};
-    const int bi = d3_b_index(wave);
-#ifdef D2_STAMP
-    StepClock clk;
-#define d3_barrier() step_barrier_clk(clk)
-#else
-#define d3_barrier() step_barrier_raw()
-#endif
-    // position in the stream of chunks (the ring has its own modulus here: NSLOT = DEPTH + 1)
-    struct Cur {
-        int c, slot, seg, rb;
-        __device__ __forceinline__ void init(int cps_) { c = 0; slot = 0; seg = 0; rb = 0; (void)cps_; }
-        __device__ __forceinline__ void next(int cps_)
-        {
-            slot = slot + 1 == NSLOT ? 0 : slot + 1;
-            rb = rb + 1;
-            if (rb == cps_) { rb = 0; seg = seg + 1; }
-            c = c + 1;
-        }
-    };
-
-    if (wave == D3_WAVE_L) {
-        // ---- loader: lane -> (row in group of 4, pol, 4 channels); one instruction = 4 rows x 64 columns of one stream
-        const int ld_row = lane >> 4, ld_pol = (lane >> 3) & 1, ld_c = cg * 32 + (lane & 7) * 4;
-        const size_t loff = (size_t)ld_pol * pol_stride + (size_t)ld_row * PB_NCHANOUT + ld_c;
-        Cur cu;
-        cu.init(cps);
-        auto fill = [&](int upto) {       // request chunks < upto
-            while (cu.c < nchunk && cu.c < upto) {
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    const float *src = Pant[st] + (size_t)cu.seg * seg_stride + (size_t)(cu.rb * T) * PB_NCHANOUT + loff;
-#pragma unroll
-                    for (int i = 0; i < T / 4; ++i)
-                        __builtin_amdgcn_global_load_lds(
-                            (const void __attribute__((address_space(1))) *)(src + (size_t)(4 * i) * PB_NCHANOUT),
-                            (void __attribute__((address_space(3))) *)&s_p[cu.slot][st][4 * i][0], 16, 0, D2_LOAD_AUX);
-                }
-                cu.next(cps);
-            }
-        };
-        // at most n chunks' loads still in flight (LPC loads each, n <= DEPTH - 1)
-        auto wait_chunks = [&](int n) {
-            if (n <= 0) wait_vmcnt<0>();
-            else if (n == 1) wait_vmcnt<LPC>();
-            else if (n == 2) wait_vmcnt<(DEPTH >= 3 ? 2 : 1) * LPC>();
-            else if (n == 3) wait_vmcnt<(DEPTH >= 4 ? 3 : 1) * LPC>();
-            else wait_vmcnt<(DEPTH - 1) * LPC>();
-        };
-        // step k: A and the B waves of parity k read chunk k's slot; chunk k + DEPTH goes into the slot chunk k - 1 had
-        // (read in step k - 1): DEPTH chunks beyond the one being read are requested
-        fill(DEPTH);
-        wait_chunks(cu.c - 1);                       // chunk 0 has landed
-        d3_barrier();
-        for (int k = 0; k < nstep; ++k) {
-            fill(k + DEPTH + 1);
-#ifdef D2_STAMP
-            const long long tw0 = D2_NOW();
-#endif
-            wait_chunks(cu.c - (k + 2));             // chunk k + 1 has landed
-#ifdef D2_STAMP
-            clk.extra += D2_NOW() - tw0;
-#endif
-            d3_barrier();
-        }
-    } else if (wave == D3_WAVE_A) {
-        // ---- A: both recurrences.  lane -> (pol, channel); registers carry (raw, excised) pairs
-        __builtin_amdgcn_s_setprio(D2_PRIO_A);
-        const int polA = lane >> 5, cA = cg * 32 + (lane & 31);
-        const float *inA[2] = {Pant[0] + (size_t)polA * pol_stride + cA, Pant[1] + (size_t)polA * pol_stride + cA};
-        float *bpp0 = a.bp + (((size_t)ant * 2 + 0) * 2 + polA) * PB_NCHANOUT + cA;
-        float *bpp1 = a.bp + (((size_t)ant * 2 + 1) * 2 + polA) * PB_NCHANOUT + cA;
-        d3f2 bp = {*bpp0, *bpp1};
-        const d3f2 sc2 = {a.scale, a.scale}, om2 = {a.oms, a.oms};
-        Cur cu;
-        cu.init(cps);
-        d3_barrier();
-        float wv_next = (lane < T && nchunk > 0) ? wrow[lane] : 1.f;
-        for (int k = 0; k < nstep; ++k) {
-            if (k < nchunk) {
-                const int slot = cu.slot, buf = k & 1;
-                {
-                    const float wv = wv_next;
-                    if (k + 1 < nchunk && lane < T) wv_next = wrow[(size_t)(k + 1) * T + lane];
-                    if (lane < T) s_w[k % 3][lane] = wv;
-                }
-                if (cu.rb == 0 && (bp.x == 0.f || bp.y == 0.f)) {
-                    // initialise the bandpass from this segment's mean (:406-411, :444-461), per stream
-                    const size_t wseg = (size_t)cu.seg * R;
-                    if (bp.x == 0.f) {
-                        const float *p = inA[0] + (size_t)cu.seg * seg_stride;
-                        float b = bp.x;
-                        for (int t = 0; t < R; ++t) b += p[(size_t)t * PB_NCHANOUT];
-                        bp.x = b / (float)R;
-                    }
-                    if (bp.y == 0.f) {
-                        const float *p = inA[1] + (size_t)cu.seg * seg_stride;
-                        float b = bp.y;
-                        int good = 0;
-                        for (int t = 0; t < R; ++t) {
-                            if (wrow[wseg + t] == 0.f) continue;
-                            good++;
-                            b += p[(size_t)t * PB_NCHANOUT];
-                        }
-                        bp.y = good == 0 ? 1.f : b / (float)good;
-                    }
-                }
-                // two batches of eight rows: sixteen (raw, excised) pairs at once would not leave 56 registers
-#pragma unroll
-                for (int hb = 0; hb < 2; ++hb) {
-                    d3f2 P[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        P[j].x = s_p[slot][0][hb * 8 + j][lane];
-                        P[j].y = s_p[slot][1][hb * 8 + j][lane];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if ((j & 3) == 0) s_ue[buf][hb * 2 + (j >> 2)][lane] = bp;      // bp before rows 0, 4, 8, 12
-                        // raw: bp = s p + (1-s) bp (:419).  excised: the same unless p > 11 bp (:490), then bp stays
-                        const d3f2 sp = sc2 * P[j];
-                        const d3f2 t = om2 * bp;
-                        const float lim = bp.y * 11.f;
-                        d3f2 n = sp + t;
-                        n.y = P[j].y > lim ? bp.y : n.y;
-                        bp = n;
-                    }
-                }
-                cu.next(cps);
-            }
-            d3_barrier();
-        }
-        *bpp0 = bp.x;
-        *bpp1 = bp.y;
-    } else {
-        // ---- B.  wave -> (chunk parity, 8-row group, stream); lane -> (half of the group's rows, channel), both pols
-        const int par = bi >> 2, g = (bi >> 1) & 1, stream = bi & 1;
-        const int half = lane >> 5, ch = lane & 31;
-        const int cB = cg * 32 + ch;
-        const int r0 = g * 8 + half * 4;
-        const float scale = a.scale, oms = a.oms;
-        uint8_t *codes = a.codes + ((size_t)ant * 2 + stream) * a.S * a.trim;
-        float *ave = a.ave ? a.ave + ((size_t)ant * 2 + stream) * a.S * a.ave_per_seg : nullptr;
-        if (a.ave_target && ant == 0 && stream == a.target_stream) ave = a.ave_target;
-        B3State<NPOL> bs;
-        Cur cu;                          // this wave's next chunk: those of its parity
-        cu.init(cps);
-        if (par) cu.next(cps);
-        // the powers of the wave's next chunk (cu), read while A works on that chunk
-        auto preload = [&]() {
-#pragma unroll
-            for (int pol = 0; pol < 2; ++pol)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bs.pn[pol][j] = s_p[cu.slot][stream][r0 + j][pol * 32 + ch];
-        };
-        auto take = [&](int c1, auto kur_tag) {
-            constexpr bool KUR = decltype(kur_tag)::value;
-            const int ub = c1 & 1;
-#pragma unroll
-            for (int pol = 0; pol < 2; ++pol) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bs.p[pol][j] = bs.pn[pol][j];
-                const d3f2 up = s_ue[ub][r0 >> 2][pol * 32 + ch];
-                bs.ub[pol] = KUR ? up.y : up.x;
-            }
-            bs.wt_sum = 0;
-            bs.wt_sumf = 0.f;
-            if (KUR) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bs.w[j] = s_w[c1 % 3][r0 + j];
-                // the group's weight sums run over all eight rows in order; the weights are the same in every lane
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const float w = s_w[c1 % 3][g * 8 + jj];
-                    const bool ok = NPOL == 1 ? (w >= 0.2f) : !(w < 0.2f);
-                    bs.wt_sum += ok ? 1 : 0;
-                    bs.wt_sumf += ok ? w : 0.f;
-                }
-            }
-            bs.trow = cu.rb * NG + g;
-            bs.seg = cu.seg;
-            d3_rows<NPOL, KUR>(bs, 0, scale, oms);
-        };
-        auto finish = [&](auto kur_tag) {
-            constexpr bool KUR = decltype(kur_tag)::value;
-            d3_rows<NPOL, KUR>(bs, 2, scale, oms);
-            float accv[2];
-#pragma unroll
-            for (int o = 0; o < NPOL; ++o) {
-                // half 0: ((((+0 + t0) + t1) + t2) + t3; half 1 goes on from its partner's sum with its own four terms
-                const float part = (((0.f + bs.term[o][0]) + bs.term[o][1]) + bs.term[o][2]) + bs.term[o][3];
-                const float got = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, part)));
-                accv[o] = (((got + bs.term[o][0]) + bs.term[o][1]) + bs.term[o][2]) + bs.term[o][3];
-            }
-            if (NPOL == 1) accv[1] = 0.f;
-            if (!KUR) {
-                accv[0] *= a.tscale;
-                accv[1] *= a.tscale;
-            } else {
-                const bool ok = (bs.wt_sumf / PB_NSCRUNCH) >= 0.2f;
-                const float d = sqrtf((float)bs.wt_sum);
-                const float q0 = accv[0] / d, q1 = accv[1] / d;
-                accv[0] = ok ? q0 : 0.f;
-                accv[1] = ok ? q1 : 0.f;
-            }
-            uint8_t *cseg = codes + (size_t)bs.seg * a.trim;
-            float *aseg = ave ? ave + (size_t)bs.seg * a.ave_per_seg : nullptr;
-            const int trow = bs.trow;
-#pragma unroll
-            for (int pol = 0; pol < NPOL; ++pol) {
-                const float acc = pol ? accv[1] : accv[0];
-                const size_t n = (NPOL == 1) ? (size_t)trow * PB_NCHANOUT + cB : ((size_t)trow * 2 + pol) * PB_NCHANOUT + cB;
-                if (aseg && half) aseg[(NPOL == 1) ? n : ((size_t)pol * ntime + trow) * PB_NCHANOUT + cB] = acc;
-                const unsigned q = quantise<NBIT>(acc);
-                if (NBIT == 8) {
-                    if (half) cseg[n] = (uint8_t)q;
-                } else if (NBIT == 4) {
-                    const unsigned hi = __shfl_down(q, 1);
-                    if (half && !(lane & 1)) cseg[n >> 1] = (uint8_t)(q | (hi << 4));
-                } else {
-                    const unsigned q1 = __shfl_down(q, 1);
-                    const unsigned q2 = __shfl_down(q, 2);
-                    const unsigned q3 = __shfl_down(q, 3);
-                    if (half && !(lane & 3)) cseg[n >> 2] = (uint8_t)(q | (q1 << 2) | (q2 << 4) | (q3 << 6));
-                }
-            }
-        };
-        d3_barrier();
-        for (int k = 0; k < nstep; ++k) {
-            // step k: chunks of this wave's parity: read the powers of chunk k (A works on it now), or take chunk k - 1
-            // (bp exports and weights are there since the last barrier) and do rows 0-1; the other steps finish the
-            // chunk taken one step before
-            if ((k & 1) == par) {
-                if (k >= 2 && k - 2 < nchunk) {
-                    if (stream) finish(std::true_type());
-                    else finish(std::false_type());
-                }
-                if (k >= 2) {
-                    cu.next(cps);
-                    cu.next(cps);
-                }
-                if (k < nchunk) preload();             // cu is chunk k now
-            } else if (k >= 1 && k - 1 < nchunk) {
-                if (stream) take(k - 1, std::true_type());
-                else take(k - 1, std::false_type());
-            }
-            d3_barrier();
-        }
-    }
-#ifdef D2_STAMP
-    if (blockIdx.x == 17 && blockIdx.z == 0 && lane == 0) {
-        g_d2_stamp[wave & 15][0] += (unsigned long long)clk.work;
-        g_d2_stamp[wave & 15][1] += (unsigned long long)clk.wait;
-        g_d2_stamp[wave & 15][2] += (unsigned long long)clk.extra;
-        g_d2_stamp[wave & 15][3] += 1ull;
-    }
-#endif
-#undef d3_barrier
-}
-
-template <int NPOL, int DEPTH>
-static void launch_d3(const Detect2Args &a, int nbit, dim3 grid, hipStream_t st)
-{
-    if (nbit == 8) k_detect3<NPOL, 8, DEPTH><<<grid, D3_THREADS, 0, st>>>(a);
-    else if (nbit == 4) k_detect3<NPOL, 4, DEPTH><<<grid, D3_THREADS, 0, st>>>(a);
-    else k_detect3<NPOL, 2, DEPTH><<<grid, D3_THREADS, 0, st>>>(a);
-}
-
 template <int T, int DEPTH>
 static void launch_all(const Detect2Args &a, int mode, int npol, int nbit, dim3 grid, hipStream_t st)
 {
@@ -1024,15 +624,6 @@ hipError_t launch_detect_pow(pb_handle *h, int nseg)
 #endif
     // three chunks in flight where detect runs wholly beside the next batch's channeliser (it flags its own rows and
     // starts straight behind the previous one), two otherwise (measured both ways, see the comment on DEPTH)
-#if PB_DETECT3
-    if (h->cfg.rfi_mode == 2 && h->R % D3_T == 0) {
-        // both streams in one workgroup: 128 workgroups of ten waves (k_detect3)
-        dim3 g3(PB_NCHANOUT / 32, 1, h->A);
-        if (h->cfg.npol == 1) launch_d3<1, D3_DEPTH>(a, h->cfg.nbit, g3, h->stream);
-        else launch_d3<2, D3_DEPTH>(a, h->cfg.nbit, g3, h->stream);
-        return hipGetLastError();
-    }
-#endif
     const int depth_env = h->sched.detect_depth;     // PB_DETECT_DEPTH 2 / 3: timing experiments
     const bool deep = depth_env ? depth_env == 3
                                 : (D2_DEPTH_OVERLAPPED == 3 && pb_fused_kurtosis(h) && h->cfg.taps == 1 && h->sets.size() >= 2 && h->A == 1);
