@@ -454,6 +454,14 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
     S = args.seg_per_step
     A = args.ant_per_gpu if ant_per_gpu is None else ant_per_gpu
     regions = args.regions if regions is None else regions
+    # No cyclic-GC pass of the interpreter inside a timed region: a full collection over the objects torch's import
+    # leaves behind takes 30-40 ms -- sixty steps' worth.  Collected HERE, before the set-up, and switched off until the
+    # timed steps are done: a 40-ms pass between staging the input and the first step (where it sat until round 5) left
+    # the GPU idle for longer than it keeps its clocks, so that the cold region measured a clock ramp the set-up's own
+    # device work had already paid for.
+    import gc
+    gc.collect()
+    gc.disable()
     if coadd is None:
         coadd = world > 1        # the incoherent sum (local sum -> reduce -> requantise on the root) is part of the step
     backend = lp.FFT_LDS if args.backend == "lds" else lp.FFT_HIPFFT
@@ -545,12 +553,7 @@ def run_chain(torch, dist, lp, args, dev, local, rank, world, taps, steps, warmu
     # then 0.64 ms per step), which is longer than a short warm-up plus a short timed region last together.  Both
     # figures are reported: the COLD region (W warm-up steps, K timed steps, nothing before them) and the sustained
     # ones (PRECONDITION_STEPS untimed steps, W warm-up steps, then `regions` timed regions of K steps back to back).
-    # No cyclic-GC pass of the interpreter inside a timed region: a full collection over the objects torch's
-    # import leaves behind takes 30-40 ms -- sixty steps' worth.  Collected here and switched off until the timed
-    # steps are done (40 ms of host work between warm-up and timing would also let the GPU clock down again).
-    import gc
-    gc.collect()
-    gc.disable()
+    # (the interpreter's garbage collector is off since the top of this function)
     h.profile(True)      # (also while warming up: the stage timers' events are created once and then reused)
 
     def fence():

@@ -150,44 +150,15 @@ __device__ __forceinline__ void dft10(f2 (&v)[10])
     }
 }
 
-// Pass-2 twiddles W^(r k) = exp(-2 pi i r k / 625), r = 1..24, k = tid mod 25 = 0..24, as an LDS table (round 6).  The
-// full [r][k] square (4800 B) does not fit beside three 50-KB workgroups per CU; W^(r k) is symmetric in (r, k), and the
-// layout below keeps every read at  per-thread base + compile-time offset  (no address arithmetic per twiddle):
-//   A     rows r = 1..12, columns c = 0..24 (200 B per row)                         r <= 12: A[r][k]   = bA + 200 (r-1)
-//   ONES  12 entries W^0 (k = 0 and r > 12)                                         r  > 12, k = 0:    ONES[r-13]
-//   B     rows k = 13..24, columns r = 13..24, row stride T2L_B_STRIDE              r  > 12, k > 12:   B[k][r]
-//         and for r > 12, 1 <= k <= 12 the transposed entry of A:                   A[k][r]            = bB + 8 r in all
-//   three cases, with bB chosen per thread once.  Same values as the global table (the host fills both from one
-//   generator, pb_api.hip: build_fft_tables), so the spectra do not change by a bit.
-#define T2L_ONES_OFF (12 * 200)
-#define T2L_B_OFF (T2L_ONES_OFF + 12 * 8)
-#ifndef T2L_B_STRIDE
-#define T2L_B_STRIDE 104       // 13 entries: rows 26 dwords apart fall on distinct banks (96 would put rows 8 apart on one)
-#endif
-#define T2L_BYTES (T2L_B_OFF + 12 * T2L_B_STRIDE)
-#ifndef FFT_T2_LDS
-#define FFT_T2_LDS 0           // 1: the channeliser kernels keep that table in LDS and fft6250 reads it there
-#endif
-
 // Complex FFT of length 6250 of the sequence whose pass-1 butterfly inputs are already in
 // v (thread tid < 250 holds z[tid + 250 r], r = 0..24).  Result Z[0..6249] in buf (natural order).
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
 
-// the table's image (global memory, T2L_BYTES) into the workgroup's LDS copy: one 16-byte load + store per thread,
-// to be called before the first barrier of the kernel
-__device__ __forceinline__ void t2lds_fill(f2 *t2lds, const void *image, int tid)
-{
-    if (tid < T2L_BYTES / 16) ((uint4 *)t2lds)[tid] = ((const uint4 *)image)[tid];
-}
-
-// in_pass3() runs after the pass-3 twiddles have been applied (their registers are free again): the
-// place for the caller to request what it needs right after the transform.
 template <class Hook = NoHook>
 __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restrict__ tw2,
-                                        const f2 *__restrict__ tw3, int tid, Hook in_pass3 = Hook(),
-                                        const f2 *t2lds = nullptr)
+                                        const f2 *__restrict__ tw3, int tid, Hook in_pass3 = Hook())
 {
     // Twiddles of the next pass are requested BEFORE the barriers that precede their use, so
     // that their L2 latency hides under this pass's arithmetic and LDS traffic.
@@ -229,22 +200,8 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
             }
         }
     };
-    // (t2lds: the pass-2 twiddles come from the workgroup's LDS table instead, read where they are used)
-    auto load_t2_lds = [&]() {
-        if (tid < 250) {
-            const char *base = (const char *)t2lds;
-            const char *bA = base + k * 8;
-            const int offB = k == 0 ? T2L_ONES_OFF - 8 * 13
-                                    : (k <= 12 ? 200 * (k - 1) : T2L_B_OFF + T2L_B_STRIDE * (k - 13) - 8 * 13);
-            const char *bB = base + offB;
-#pragma unroll
-            for (int r = 1; r <= 12; ++r) t2[r - 1] = *(const f2 *)(bA + 200 * (r - 1));
-#pragma unroll
-            for (int r = 13; r <= 24; ++r) t2[r - 1] = *(const f2 *)(bB + 8 * r);
-        }
-    };
 #if FFT_PREFETCH & 1
-    if (!t2lds) load_t2();
+    load_t2();
 #endif
     // pass 1: R = 25, Ns = 1
     if (tid < 250) {
@@ -261,11 +218,10 @@ __device__ __forceinline__ void fft6250(f2 (&v)[25], f2 *buf, const f2 *__restri
 #pragma unroll
         for (int r = 0; r < 25; ++r) v[r] = buf[tid + 250 * r];
     }
-    if (t2lds) load_t2_lds();      // (read-only table: no barrier needed, the waits run under the one below)
     __syncthreads();
     FFT_STAMP(4);
 #if !(FFT_PREFETCH & 1)
-    if (!t2lds) load_t2();
+    load_t2();
 #endif
 #if FFT_PREFETCH & 2
     load_t3();

@@ -60,7 +60,6 @@ struct ChanArgs {
     float *Praw, *Pkur;     // [A][S][2][R][4096]
     size_t p_ant_stride;
     const float2 *tw2, *tw3, *post;
-    const float2 *tw2s;     // image of the LDS pass-2 twiddle table (FFT_T2_LDS)
     const float2 *postc;    // post[2155..6250], 16-byte aligned copy
     FrbParams frb;          // delays == nullptr: no injection
     int R, rfi_mode, inject_now;
@@ -127,7 +126,7 @@ template <int ROLE, bool FIX = false, bool DEFER = false>
 __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int tid, int seg, int row, int pol, int ant,
                                                 RowStage &st, unsigned mask, float wrow, size_t prow, int next_row,
                                                 int next_pol = -1, bool prestaged = false,
-                                                const unsigned *smw = nullptr, int after_row = -1, const f2 *t2lds = nullptr)
+                                                const unsigned *smw = nullptr, int after_row = -1)
 {
     if (next_pol < 0) next_pol = pol;
     FFT_STAMP(0);
@@ -182,7 +181,7 @@ __device__ __forceinline__ void channelize_pass(const ChanArgs &a, f2 *buf, int 
         for (int r = 0; r < 25; ++r) buf[tid * 25 + r] = v[r];
     __syncthreads();
 #else
-    fft6250(v, buf, (const f2 *)a.tw2, (const f2 *)a.tw3, tid, load_tq, t2lds);
+    fft6250(v, buf, (const f2 *)a.tw2, (const f2 *)a.tw3, tid, load_tq);
 #endif
     if (DEFER) {
         // (written by wave 0 before the barrier in front of pass 1)
@@ -292,13 +291,6 @@ __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
 {
     __shared__ __attribute__((aligned(16))) f2 buf[M_HALF];
 #endif
-#if FFT_T2_LDS && !defined(FFT_LEAN)
-    __shared__ __attribute__((aligned(16))) f2 t2tab[T2L_BYTES / 8];
-    t2lds_fill(t2tab, a.tw2s, threadIdx.x);
-    const f2 *t2lds = t2tab;
-#else
-    const f2 *t2lds = nullptr;
-#endif
     FFT_STAMP(8);
     int tid = threadIdx.x;
     // grid (ceil(R / CH_ROWS), nseg * 2, A): no division to find the rows
@@ -331,8 +323,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
         const bool second = a.rfi_mode == 1 || (a.rfi_mode == 2 && mask != 0);
         if (i) __syncthreads();   // the previous transform has finished reading buf
         if (a.rfi_mode != 1) {
-            channelize_pass<0>(a, buf, tid, seg, row, pol, ant, st, mask, wrow, prow, second && !all_bad ? row : after, -1,
-                               false, nullptr, -1, t2lds);
+            channelize_pass<0>(a, buf, tid, seg, row, pol, ant, st, mask, wrow, prow, second && !all_bad ? row : after);
             if (!second) continue;
         }
         if (all_bad) {
@@ -347,7 +338,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize(ChanArgs a)
             __syncthreads();   // the raw pass has finished reading buf
             asm volatile("" : "+v"(tid));   // no sharing of tid-derived addresses across the two passes
         }
-        channelize_pass<1>(a, buf, tid, seg, row, pol, ant, st, mask, wrow, prow, after, -1, false, nullptr, -1, t2lds);
+        channelize_pass<1>(a, buf, tid, seg, row, pol, ant, st, mask, wrow, prow, after);
     }
 }
 
@@ -377,13 +368,6 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
 {
     __shared__ __attribute__((aligned(16))) f2 buf[M_HALF];
     __shared__ unsigned smw[2];     // the row's flag mask and weight bits (outside buf: the transforms overwrite that)
-#if FFT_T2_LDS
-    __shared__ __attribute__((aligned(16))) f2 t2tab[T2L_BYTES / 8];
-    t2lds_fill(t2tab, a.tw2s, threadIdx.x);
-    const f2 *t2lds = t2tab;
-#else
-    const f2 *t2lds = nullptr;
-#endif
 #ifdef KUR_STAMP
     __shared__ unsigned long long kts[8];
 #endif
@@ -481,7 +465,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
         if (a.rfi_mode != 1) {
             // what is requested while this transform is in its spectrum step -- the same row again for its excised
             // transform, else pol 1's row -- is decided inside, once the mask is known
-            channelize_pass<0, true, true>(a, buf, tid, seg, row, pol, ant, st, 0u, 0.f, prow, -1, 1, pol == 0, smw, after_row, t2lds);
+            channelize_pass<0, true, true>(a, buf, tid, seg, row, pol, ant, st, 0u, 0.f, prow, -1, 1, pol == 0, smw, after_row);
             mask = __builtin_amdgcn_readfirstlane(smw[0]);
             wrow = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(smw[1]));
         }
@@ -499,7 +483,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize_kur(ChanArgs a)
         }
         // (RFI mode 1, pol 0: the bytes the statistic staged are still where this transform expects them)
         channelize_pass<1, true>(a, buf, tid, seg, row, pol, ant, st, mask, wrow, prow, after_row, 1,
-                                 a.rfi_mode == 1 && pol == 0, nullptr, -1, t2lds);
+                                 a.rfi_mode == 1 && pol == 0);
     }
 #ifdef KUR_STAMP
     if (threadIdx.x == 0 && blockIdx.z == 0) {
@@ -558,7 +542,6 @@ hipError_t launch_channelize(pb_handle *h, int nseg, int inject_now)
     a.Pkur = h->d_Pkur;
     a.p_ant_stride = (size_t)h->S * 2 * h->R * PB_NCHANOUT;
     a.tw2 = h->ft.tw2;
-    a.tw2s = h->ft.tw2s;
     a.tw3 = h->ft.tw3;
     a.post = h->ft.post;
     a.postc = h->ft.postc;

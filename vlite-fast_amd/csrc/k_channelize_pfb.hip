@@ -56,7 +56,6 @@ struct PfbArgs {
     float *Praw, *Pkur;
     size_t p_ant_stride;
     const float2 *tw2, *tw3, *postc;
-    const float2 *tw2s;      // image of the LDS pass-2 twiddle table (FFT_T2_LDS)
     FrbParams frb;
     int R, rfi_mode, inject_now;
 };
@@ -78,8 +77,7 @@ __device__ __forceinline__ unsigned row_mask(const PfbArgs &a, int ant, int rr)
 // rows' bytes run side by side.
 template <int role>
 __device__ __forceinline__ void pfb_pass(const PfbArgs &a, uint8_t *lds, int tid, int grow, int seg, int row, int pol,
-                                         int ant, const unsigned (&mask)[4], unsigned differ, float w, size_t prow,
-                                         const f2 *t2lds)
+                                         int ant, const unsigned (&mask)[4], unsigned differ, float w, size_t prow)
 {
     f2 *buf = (f2 *)lds;
     // window coefficients of samples (2n, 2n+1), n = tid + 250 r, tap j: through a buffer descriptor
@@ -212,7 +210,7 @@ __device__ __forceinline__ void pfb_pass(const PfbArgs &a, uint8_t *lds, int tid
             tq[i][1] = *(const float4 *)(a.postc + tid * 4 + 1024 * i + 2);
         }
     };
-    fft6250(v, buf, (const f2 *)a.tw2, (const f2 *)a.tw3, tid, load_tq, t2lds);
+    fft6250(v, buf, (const f2 *)a.tw2, (const f2 *)a.tw3, tid, load_tq);
 
     const bool inject = a.frb.delays != nullptr && a.inject_now > 0;
     const int since = inject ? (a.inject_now - 1 + seg) * a.R : 0;
@@ -260,13 +258,6 @@ __device__ __forceinline__ void pfb_pass(const PfbArgs &a, uint8_t *lds, int tid
 __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4 * PFB_ROW_LDS];   // 50 112 B, reused as the FFT buffer
-#if FFT_T2_LDS
-    __shared__ __attribute__((aligned(16))) f2 t2tab[T2L_BYTES / 8];
-    t2lds_fill(t2tab, a.tw2s, threadIdx.x);
-    const f2 *t2lds = t2tab;
-#else
-    const f2 *t2lds = nullptr;
-#endif
     int tid = threadIdx.x;
     // grid (R, nseg * 2, A): no division to find the row.  Workgroups go to the 8 XCDs in turn, and an input row
     // is read by the workgroups of four consecutive output rows: give every XCD a contiguous eighth of the
@@ -294,7 +285,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
         }
     }
     const size_t prow = (size_t)ant * a.p_ant_stride + (((size_t)seg * 2 + pol) * a.R + row) * PB_NCHANOUT;
-    if (a.rfi_mode != 1) pfb_pass<0>(a, lds, tid, grow, seg, row, pol, ant, mask, differ, w, prow, t2lds);
+    if (a.rfi_mode != 1) pfb_pass<0>(a, lds, tid, grow, seg, row, pol, ant, mask, differ, w, prow);
     if (a.rfi_mode == 0 || (a.rfi_mode == 2 && differ == 0)) return;
     if (w == 0.f) {
         for (int c = tid; c < PB_NCHANOUT; c += 256) a.Pkur[prow + c] = __builtin_inff();
@@ -304,7 +295,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize_pfb(PfbArgs a)
         __syncthreads();   // the raw pass has finished reading the FFT buffer
         asm volatile("" : "+v"(tid));   // no sharing of tid-derived addresses across the two passes
     }
-    pfb_pass<1>(a, lds, tid, grow, seg, row, pol, ant, mask, differ, w, prow, t2lds);
+    pfb_pass<1>(a, lds, tid, grow, seg, row, pol, ant, mask, differ, w, prow);
 }
 
 
@@ -394,7 +385,6 @@ hipError_t launch_channelize_pfb(pb_handle *h, int nseg, int inject_now)
     a.Pkur = h->d_Pkur;
     a.p_ant_stride = (size_t)h->S * 2 * h->R * PB_NCHANOUT;
     a.tw2 = h->ft.tw2;
-    a.tw2s = h->ft.tw2s;
     a.tw3 = h->ft.tw3;
     a.postc = h->ft.postc;
     a.frb.delays = (inject_now > 0) ? h->d_frb_delays : nullptr;

@@ -8,7 +8,6 @@
 
 #include "kurtosis_dev.h"
 #include "pb_internal.h"
-#include "fft_lds.h"   // T2L_*: layout of the LDS twiddle table whose image build_fft_tables fills
 
 static std::string g_create_err;
 static void drain_timers(pb_handle *h);
@@ -232,17 +231,6 @@ static int build_fft_tables(pb_handle *h)
         post[k] = make_float2((float)(-sin(a)), (float)(-cos(a)));
     }
     FftTables &t = h->ft;
-    {
-        // the pass-2 twiddles again, as the image of the LDS table of fft_lds.h (T2L_*): same generator, same values
-        std::vector<float2> img(T2L_BYTES / 8, make_float2(0.f, 0.f));
-        for (int r = 1; r <= 12; ++r)
-            for (int c = 0; c < 25; ++c) img[(200 * (r - 1)) / 8 + c] = cis_neg((double)(r * c), 625.0);
-        for (int j = 0; j < 12; ++j) img[T2L_ONES_OFF / 8 + j] = cis_neg(0.0, 625.0);
-        for (int k = 13; k <= 24; ++k)
-            for (int r = 13; r <= 24; ++r) img[(T2L_B_OFF + T2L_B_STRIDE * (k - 13)) / 8 + (r - 13)] = cis_neg((double)(r * k), 625.0);
-        HIPCHK(h, dmalloc(h, &t.tw2s, img.size()));
-        HIPCHK(h, hipMemcpy(t.tw2s, img.data(), img.size() * sizeof(float2), hipMemcpyHostToDevice));
-    }
     HIPCHK(h, dmalloc(h, &t.tw2, 600));
     HIPCHK(h, dmalloc(h, &t.tw3, 6250));
     HIPCHK(h, dmalloc(h, &t.post, PB_NCHAN));
@@ -568,7 +556,7 @@ extern "C" void pb_destroy(pb_handle *h)
         if (h->h_codes) (void)hipHostFree(h->h_codes);
     }
     void *ptrs[] = {h->d_vdif, h->d_frame_idx, h->d_bp, h->d_frb_delays, h->d_hist_in, h->d_hist_flags,
-                    h->d_hist_valid, h->d_tapE, h->d_dag, h->ft.tw2, h->ft.tw2s,
+                    h->d_hist_valid, h->d_tapE, h->d_dag, h->ft.tw2,
                     h->ft.tw3, h->ft.post, h->ft.postc, h->ft.taps, h->ft.taps_n};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

@@ -35,7 +35,6 @@ struct FrbParams {
 // are compile-time literals (fft_consts.h)
 struct FftTables {
     float2 *tw2;    // [12 pairs (r, r+1)][25 k][2]   pass-2 twiddles exp(-2 pi i r k / 625), r = 1..24 (fft_lds.h: load_t2)
-    float2 *tw2s;   // the same twiddles as the image of the channelisers' LDS table (fft_lds.h: T2L_*), T2L_BYTES
     float2 *tw3;    // [625 j][10]    pass-3 twiddles exp(-2 pi i r j / 6250), r = 1..9, one pad
     float2 *post;   // [6251]
     float2 *postc;  // [4096] = post[2155..6250], its own 16-byte aligned allocation
