@@ -758,6 +758,8 @@ def build_parser():
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the ranks --gpus N starts (0: pick one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power", action="store_true", help="skip the 2-s power / clock / throttle sample (roofline.power)")
+    ap.add_argument("--no-residency", action="store_true",
+                    help="skip roofline.residency (its in-run form starts a child process: not wanted under a profiler)")
     ap.add_argument("--no-extras", action="store_true", help="skip the taps4 / ingest / search / configs3 sub-records")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="with --coadd-selftest: also run the ROOT's tree over this many gathered planes per step (timing of "
@@ -984,7 +986,7 @@ def rank_body(args, rank, world, local, cpu, torch, dist, dev, ndev):
                     out["roofline"]["power"] = power_record(torch, lp, args, dev, local, args.taps)
                 except Exception as e:
                     out["roofline"]["power"] = {"error": str(e)}
-            out["roofline"]["residency"] = residency_record()
+            out["roofline"]["residency"] = None if args.no_residency else residency_record()
             try:
                 pw = out["roofline"].get("power") or {}
                 out["roofline"]["valu"] = valu_record(args, args.taps, r["ms_per_step"], pw.get("gfx_mhz"))

@@ -419,3 +419,65 @@ def test_incoherent_coadd_source_switch():
     cf = coadd.IncoherentCoadd(hf, 2, "cpu", backend="gloo", order="fast")
     cf.step(SEG)
     assert "coadd_local" in [x[0] for x in hf.calls]
+
+
+def test_threaded_ranks_transport_and_the_leg_checks():
+    """The rehearsal transport itself (vlite-fast_amd/threaded_ranks.py): ranks see their own rank, collectives move what
+    torch.distributed says they move, a failing rank's exception reaches the caller (and does not hang the others) --
+    and IncoherentCoadd's checks inside such a world: a handle with another antenna count than a mod world gives the
+    rank is refused for EVERY world size (it would mis-address the root's leaves, or write past the shipped planes, in a
+    world that is not a power of two), `parts` (timing experiments) never runs the sliced layout, the threaded group
+    offers no dist.reduce so order="fast" is refused there."""
+    import torch
+    tr = importlib.import_module("vlite-fast_amd.threaded_ranks")
+    coadd = importlib.import_module("vlite-fast_amd.coadd")
+
+    def body(rank, world, dist):
+        assert dist.get_rank() == rank and dist.get_world_size() == world and dist.get_backend() == "threaded"
+        t = torch.arange(world * 2, dtype=torch.float32) + 100 * rank
+        o = torch.empty_like(t)
+        dist.all_to_all_single(o, t)
+        assert o.tolist() == [100 * s + 2 * rank + i for s in range(world) for i in range(2)]
+        mine = torch.full((3,), rank, dtype=torch.uint8)
+        into = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, into, dst=0)
+        out = {"gathered": [int(x[0]) for x in into] if rank == 0 else None}
+        # the leg's checks (world 3: not a power of two -> every antenna's plane is shipped)
+        n_mine = len(coadd.antennas_of_rank(7, rank, world))
+        ok = coadd.IncoherentCoadd(FakeCoaddHandle(n_mine), 7, "cpu", backend="threads")
+        out["layout"], out["ship"] = ok.layout, ok.ship
+        for bad_n in (n_mine + 1, n_mine - 1):
+            if bad_n >= 1:
+                with pytest.raises(ValueError, match="sharding"):
+                    coadd.IncoherentCoadd(FakeCoaddHandle(bad_n), 7, "cpu", backend="threads")
+        with pytest.raises(ValueError, match="dist.reduce"):
+            coadd.IncoherentCoadd(FakeCoaddHandle(n_mine), 7, "cpu", backend="threads", order="fast")
+        dist.barrier()
+        return out
+
+    res = tr.run_as_threads(3, body, timeout=120)
+    assert res[0]["gathered"] == [0, 1, 2] and all(r["layout"] == "root" and r["ship"] == 3 for r in res)
+
+    def body4(rank, world, dist):
+        h = FakeCoaddHandle(1)
+        with pytest.raises(ValueError, match="parts"):
+            coadd.IncoherentCoadd(h, 4, "cpu", backend="threads", layout="sliced", parts=1)
+        a = coadd.IncoherentCoadd(FakeCoaddHandle(1), 4, "cpu", backend="threads", parts=1)       # auto + parts -> root
+        b = coadd.IncoherentCoadd(FakeCoaddHandle(1), 4, "cpu", backend="threads")
+        return a.layout, b.layout
+
+    assert tr.run_as_threads(4, body4, timeout=120) == [("root", "sliced")] * 4
+
+    def failing(rank, world, dist):
+        if rank == 1:
+            raise KeyError("rank one gives up")
+        dist.barrier()                       # the others wait here; the group's termination event releases them
+        return rank
+
+    with pytest.raises(RuntimeError, match="threaded rank 1 failed"):
+        tr.run_as_threads(3, failing, timeout=120)
+    # and the process-wide torch.distributed state is as it was: no group left installed, and a run after a failed one
+    # works (the group's termination event does not outlive the run that set it)
+    import torch.distributed as dist
+    assert not dist.is_initialized()
+    assert tr.run_as_threads(3, lambda rank, world, d: (d.barrier(), rank)[1], timeout=120) == [0, 1, 2]

@@ -14,6 +14,6 @@ for grp in "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ
            "SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY" \
            "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY"; do
     i=$((i+1))
-    rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -- python3 bench.py --steps 8 --warmup 4 --regions 1 --no-cpu-baseline "$@" > /dev/null 2> $OUT/g$i.err
+    rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -- python3 bench.py --steps 8 --warmup 4 --regions 1 --no-cpu-baseline --no-residency "$@" > /dev/null 2> $OUT/g$i.err
 done
 echo counters $TAG

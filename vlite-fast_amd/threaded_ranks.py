@@ -26,6 +26,7 @@ def run_as_threads(world, body, timeout=None):
     import torch.distributed as dist
     from torch.testing._internal.distributed import multi_threaded_pg as tpg
 
+    tpg.ProcessLocalGroup.reset()           # (a termination event left by a run that failed would end this one at once)
     tpg._install_threaded_pg()
     torch._C._distributed_c10d._set_thread_isolation_mode(True)
     store = dist.HashStore()
@@ -59,7 +60,11 @@ def run_as_threads(world, body, timeout=None):
     finally:
         torch._C._distributed_c10d._set_thread_isolation_mode(False)
         tpg._uninstall_threaded_pg()
+        tpg.ProcessLocalGroup.reset()
     if errors:
-        rank, e, tb = sorted(errors, key=lambda x: x[0])[0]
+        # the rank that failed FIRST and on its own account: the ranks the group's termination event then releases
+        # from their collectives leave with a SystemExit of their own
+        own = [x for x in errors if not isinstance(x[1], SystemExit)] or errors
+        rank, e, tb = own[0]
         raise RuntimeError("threaded rank %d failed: %r" % (rank, e)).with_traceback(tb)
     return results
