@@ -79,3 +79,23 @@ def test_gpus2_starts_two_ranks_and_relays_their_failure():
     assert p.returncode != 0
     assert p.stdout.strip() == "" or "n_gpus" not in p.stdout
     assert "GPU" in p.stderr
+
+
+def test_threaded_rehearsal_is_refused_without_share_gpus_and_without_a_gpu():
+    """`--dist-backend threads` (the N ranks as threads of one process on ONE card) is a rehearsal by construction: both
+    bench.py and the coadder host insist on --share-gpus for it, start no child ranks, and -- like every other path --
+    refuse to run without a GPU instead of falling back to anything."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dist-backend", "threads", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "--share-gpus" in p.stderr and "torch.distributed.run" not in p.stderr
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "vlite-fast_amd", "coadd_host.py"), "--ranks", "8", "--dist-backend", "threads",
+                        "--replay"] + ["x.uw"] * 8, env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        assert q.returncode != 0 and "--share-gpus" in q.stderr
+    else:
+        assert q.returncode != 0 and ("needs a GPU" in q.stderr or "--share-gpus" in q.stderr)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dist-backend", "threads", "--share-gpus",
+                            "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "needs a GPU" in r.stderr and "n_gpus" not in r.stdout
