@@ -27,6 +27,8 @@ __global__ void k_hold(uint64_t ticks, unsigned *sink)
 // vector instructions at a given duty: `burst` dependent-free packed FMAs, then s_sleep(idle)
 __global__ void k_valu(uint64_t ticks, int burst, int idle, float *sink)
 {
+    extern __shared__ unsigned vsm[];          // (optional dynamic LDS: the footprint of a small workgroup that also computes)
+    if (threadIdx.x == 0) vsm[0] = 1;
     float a0 = threadIdx.x, a1 = 1.f, a2 = 2.f, a3 = 3.f;
     const float m = 1.0000001f, c = 1e-9f;
     const uint64_t t_end = now100() + ticks;
@@ -93,7 +95,14 @@ extern "C" int corun_hold(void *stream, int nwg, int threads, int lds_bytes, dou
 }
 extern "C" int corun_valu(void *stream, int nwg, int threads, int burst, int idle, double ms, void *sink)
 {
-    k_valu<<<nwg, threads, 0, (hipStream_t)stream>>>((uint64_t)(ms * 1e5), burst, idle, (float *)sink);
+    k_valu<<<nwg, threads, 16, (hipStream_t)stream>>>((uint64_t)(ms * 1e5), burst, idle, (float *)sink);
+    return (int)hipGetLastError();
+}
+// the same with `lds_bytes` of LDS held
+extern "C" int corun_valu_lds(void *stream, int nwg, int threads, int burst, int idle, int lds_bytes, double ms, void *sink)
+{
+    (void)hipFuncSetAttribute((const void *)k_valu, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    k_valu<<<nwg, threads, lds_bytes, (hipStream_t)stream>>>((uint64_t)(ms * 1e5), burst, idle, (float *)sink);
     return (int)hipGetLastError();
 }
 extern "C" int corun_ldsbw(void *stream, int nwg, int threads, int idle, double ms, void *sink)

@@ -30,13 +30,15 @@ co = C.CDLL(os.path.join(ROOT, "build", "libcorun.so"))
 vp = C.c_void_p
 co.corun_hold.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, vp]
 co.corun_valu.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp]
+co.corun_valu_lds.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp]
 co.corun_ldsbw.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, vp]
 co.corun_hbm.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t, C.c_int, C.c_double, vp, vp]
 
 dev = torch.device("cuda", 0)
 S, NSETS = 10, 3
 A = int(os.environ.get("CORUN_ANTS", "1"))
-h = lp.PbHandle(device=0, nant=A, nbit=8, npol=1, rfi_mode=2, rows_per_seg=1024, max_seg=S, nsets=NSETS)
+h = lp.PbHandle(device=0, nant=A, nbit=8, npol=1, rfi_mode=2, rows_per_seg=1024, max_seg=S, nsets=NSETS,
+                taps=int(os.environ.get("CORUN_TAPS", "1")))
 for a in range(A):
     sec = synth_second(torch, dev, 42 + a, h.seg_samples, S)
     torch.cuda.synchronize()
@@ -70,6 +72,8 @@ def launch(kind, ms):
         rc = co.corun_hold(s, kind[1], kind[2], kind[3], ms, sink.data_ptr())
     elif k == "valu":
         rc = co.corun_valu(s, kind[1], kind[2], kind[3], kind[4], ms, sink.data_ptr())
+    elif k == "valulds":      # valulds,nwg,threads,burst,idle,lds_bytes
+        rc = co.corun_valu_lds(s, kind[1], kind[2], kind[3], kind[4], kind[5], ms, sink.data_ptr())
     elif k == "ldsbw":
         rc = co.corun_ldsbw(s, kind[1], kind[2], kind[3], ms, sink.data_ptr())
     elif k == "hbm":
