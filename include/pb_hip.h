@@ -263,7 +263,11 @@ int pb_channelize_f32(pb_handle *h, const float *x, int nrows, int taps, float *
  * Brute-force incoherent dedispersion over a linear DM grid + boxcar matched filter on a block of
  * filterbank codes (SIGPROC order [time][channel], 8/4/2 bit).  Delay constant 4.148808e3 MHz^2 s
  * (src/candidate.py:33); reference = top of the band.  zap_ranges: nzap pairs [lo, hi) of channels
- * to ignore (heimdall's -zap_chans).  Parity with heimdall: unpinned (third-party, absent). */
+ * to ignore (heimdall's -zap_chans).  Parity with heimdall: unpinned (third-party, absent).
+ * The band, the sample time and the DM grid are binary32 in this interface (SIGPROC headers carry doubles: the caller
+ * rounds); the delays are floor(x + 0.5) of the formula evaluated in DOUBLE from those rounded values, DM i of the grid
+ * being (double)dm_min + i * (double)dm_step -- a checker must round its parameters the same way, or a delay within
+ * 1e-7 of a half sample lands on the other side (tests/test_gpu_search.py: random geometries). */
 typedef struct pb_search pb_search;
 int pb_search_create(int device, int nchan, int max_samples, float fch1_mhz, float foff_mhz, float tsamp_s,
                      float dm_min, float dm_max, float dm_step, int boxcar_max, const int *zap_ranges,

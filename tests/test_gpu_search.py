@@ -258,3 +258,43 @@ def test_dm_list_and_the_search_cli_on_a_fil(tmp_path, capsys):
     assert abs(float(best[5]) - dm) < 15 and abs(int(best[1]) - t0) <= 4          # DM and stream sample of the pulse
     assert len(got) >= 1 and got[0].split("\n")[0].split()[0] == "2016-07-01-01:00:00" and got[0].split("\n")[0].split()[3] == "8"
     assert any(l.split()[1] == best[1] for g in got for l in g.split("\n")[2:] if l.strip())
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_search_geometries_dedisperse_exactly(oracle, seed):
+    """Seeded random geometries of the dedispersion stage -- channel count, band, block length (also a few samples past a
+    tile boundary), DM grid, zapped ranges (none, edges, a notch), boxcar count -- against oracle.dedisperse_series
+    (exact integers, analysis/loc_step0.py:44-66 with the delay of src/candidate.py:33) and oracle.boxcar_best on every
+    trial DM (the kernel's own level and rms)."""
+    rng = np.random.default_rng(4000 + seed)
+    nchan = int(rng.choice([64, 96, 128, 256, 512]))
+    # the C ABI carries the band and the sample time as binary32 (include/pb_hip.h: pb_search_create): the delays are
+    # those of the ROUNDED parameters, evaluated in double -- a delay that falls within 1e-7 of a half-sample rounds
+    # the other way otherwise (seen with seed 7 before the parameters were rounded here: one channel of one trial DM)
+    fch1 = float(np.float32(rng.uniform(340.0, 384.0)))
+    foff = float(np.float32(-float(rng.uniform(32.0, 64.0)) / nchan))
+    tsamp = float(np.float32(search.TSAMP))
+    dm_max = float(rng.choice([20.0, 60.0, 150.0]))
+    dm_step = float(rng.choice([2.0, 5.0, 10.0]))
+    boxcar_max = int(rng.choice([1, 4, 16, 64]))
+    zaps = [(), ((0, 5), (nchan - 7, nchan)), ((nchan // 3, nchan // 3 + 9),)][int(rng.integers(0, 3))]
+    with search.Searcher(nchan=nchan, max_samples=8192, fch1=fch1, foff=foff, tsamp=tsamp, dm_min=0.0, dm_max=dm_max,
+                         dm_step=dm_step, boxcar_max=boxcar_max, zap=zaps) as s0:
+        maxd = s0.max_delay
+    T = maxd + int(rng.choice([64, 71, 2048, 2049, 2056, 3000]))      # (a block yields at least 64 samples)
+    codes = rng.integers(0, 256, (T, nchan)).astype(np.uint8)
+    with search.Searcher(nchan=nchan, max_samples=T, fch1=fch1, foff=foff, tsamp=tsamp, dm_min=0.0, dm_max=dm_max,
+                         dm_step=dm_step, boxcar_max=boxcar_max, zap=zaps) as s:
+        assert s.max_delay == maxd
+        r = s.run(codes, want_series=True)
+        dms, nbox = s.dms, s.nbox
+    zmask = np.zeros(nchan, bool)
+    for lo, hi in zaps:
+        zmask[lo:hi] = True
+    delays = oracle.search_delays(dms, fch1, foff, nchan, tsamp)
+    ref, tout = oracle.dedisperse_series(codes, delays, zmask)
+    assert tout == r["tout"] == T - maxd and np.array_equal(r["series"], ref), (nchan, T, dm_max, dm_step, zaps)
+    for i in range(len(dms)):
+        mean, rms = r["stats"][i]
+        best, bw = oracle.boxcar_best(ref[i], mean, rms, nbox)
+        np.testing.assert_allclose(r["snr"][i], best, rtol=3e-5, atol=3e-4)
