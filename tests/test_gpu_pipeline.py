@@ -190,3 +190,49 @@ def test_profile_pass_logs_the_stage_lines(tmp_path):
         assert label in log
     import re
     assert re.search(r"FFT\.+([0-9]+\.[0-9]{3})\n", log)          # seconds, %.3f like the reference (tiny here)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_gpu_vdif_gather_random_loss_patterns(seed):
+    """Seeded random damage to one second of frames -- frames dropped, frames repeated, the invalid-data bit set, the
+    order shuffled (the first frame stays: it anchors the block) -- through pb_submit_vdif (host frame index + the
+    gather kernel, in place of the demux loop of src/process_baseband.cu:1015-1067) against the host deframer on the same
+    bytes fed through pb_submit_planar: identical filterbank bytes, both streams."""
+    lp = libpb()
+    rng = np.random.default_rng(900 + seed)
+    data = make_input(40 + seed, R, SEG, rfi=bool(rng.integers(0, 2)), dropped=False)
+    p0 = np.concatenate([data[i, 0] for i in range(SEG)])
+    p1 = np.concatenate([data[i, 1] for i in range(SEG)])
+    blk = vdif.frame_block(p0, p1, 3600, 33, 7).reshape(-1, 5032).copy()
+    nfr = blk.shape[0]
+    # a block always holds a second's worth of slots (the host seals it that way): a LOST frame is a slot that holds
+    # something else -- a repeat of another frame of the second (lands where that one lands: harmless) or a frame of
+    # another second (outside the block's span: ignored); its own place stays zero
+    damaged = blk.copy()
+    lost = 1 + rng.choice(nfr - 1, size=int(rng.integers(0, nfr // 4)), replace=False)
+    for i in lost:
+        if rng.integers(0, 2):
+            damaged[i] = blk[int(rng.integers(0, nfr))]
+        else:
+            w = damaged[i, :4].view("<u4").copy()
+            w[0] = (w[0] & ~np.uint32(0x3FFFFFFF)) | np.uint32(3600 + int(rng.integers(1, 5)))
+            damaged[i, :4] = w.view(np.uint8)
+    keep = np.ones(nfr, bool)
+    keep[lost] = False
+    dup = lost
+    rest = np.arange(1, nfr)
+    rng.shuffle(rest)
+    damaged = damaged[np.concatenate([[0], rest])].copy()
+    for v in rng.choice(np.arange(1, damaged.shape[0]), size=int(rng.integers(0, 5)), replace=False):
+        damaged[v, 3] |= 0x80                                          # invalid-data bit -> zero fill
+    ref = vdif.deframe_block(damaged.ravel())
+    with lp.PbHandle(nbit=8, rows_per_seg=R, max_seg=SEG) as h1, lp.PbHandle(nbit=8, rows_per_seg=R, max_seg=SEG) as h2:
+        h1.submit_vdif(0, 0, damaged.ravel())
+        h1.process(SEG)
+        a = h1.fetch(0, 0, SEG)
+        n = R * 12500
+        for s in range(SEG):
+            h2.submit_planar(0, s, ref[0, s * n:(s + 1) * n], ref[1, s * n:(s + 1) * n])
+        h2.process(SEG)
+        b = h2.fetch(0, 0, SEG)
+    assert np.array_equal(a["raw"], b["raw"]) and np.array_equal(a["kur"], b["kur"]), (seed, int((~keep).sum()), dup.size)
